@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY — generates the committed golden fixtures under tests/golden/
+by running the *compiled reference* (oracle/_ref/mmannot*, built by oracle/build_ref.sh from
+/root/reference/mmannot.cpp) in the build container.  Only derived data is written: sorted
+interval dumps, alignment tuples, count tables, stderr statistics, per-hit region sets.
+No reference source or script text is stored.
+
+Usage:  python oracle/gen_golden.py [test_dataset] [kat] [synth]
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import mm_oracle as mo  # noqa: E402
+
+REF = os.environ.get("REF", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+AMB_CONFIG = """Introns:
+protein_coding:gene
+Vicinity:
+protein_coding:gene
+Order:
+protein_coding:CDS,protein_coding:5'UTR,protein_coding:3'UTR
+rRNA:gene,snRNA:gene,misc_RNA:gene,lincRNA:gene
+processed_pseudogene:gene -,unprocessed_pseudogene:gene +,protein_coding:intron
+protein_coding:upstream,protein_coding:downstream,protein_coding:gene
+"""
+
+
+def write_iv_dump(iv, path):
+    with gzip.open(path, "wt") as f:
+        f.write("#idx\tchrId\tchrName\tstart\tend\ttype\tstrand\tid\n")
+        for i in range(len(iv["start"])):
+            f.write(f"{i}\t{iv['chr'][i]}\t{iv['chr_name'][i]}\t{iv['start'][i]}\t{iv['end'][i]}\t{iv['type'][i]}\t{iv['strand'][i]}\t{iv['id'][i]}\n")
+
+
+def gen_test_dataset():
+    out = os.path.join(GOLD, "test_dataset")
+    os.makedirs(out, exist_ok=True)
+    gtf = os.path.join(REF, "test_dataset.gtf")
+    bam = os.path.join(REF, "test_dataset.bam")
+    tmp = tempfile.mkdtemp(prefix="mmgold")
+    amb_cfg = os.path.join(tmp, "cfg_amb.txt")
+    open(amb_cfg, "w").write(AMB_CONFIG)
+    configs = {"hs38": os.path.join(REF, "configHS38.txt"), "amb": amb_cfg}
+    for k, p in configs.items():
+        desc = mo.parse_config_order(open(p).read())
+        json.dump(desc.to_json(), open(os.path.join(out, f"config_{k}.json"), "w"), indent=0)
+    json.dump({"amb_config_text": AMB_CONFIG}, open(os.path.join(out, "config_amb_text.json"), "w"))
+
+    # (case name, variant, config key, extra args)
+    cases = [
+        ("U_default", "mmannot_dump", "hs38", ["-s", "U"]),
+        ("U_l0", "mmannot_dump", "hs38", ["-s", "U", "-l", "0"]),
+        ("U_l1", "mmannot_dump", "hs38", ["-s", "U", "-l", "1"]),
+        ("U_l10", "mmannot_dump", "hs38", ["-s", "U", "-l", "10"]),
+        ("U_l0.5", "mmannot_dump", "hs38", ["-s", "U", "-l", "0.5"]),
+        ("U_l0.99", "mmannot_dump", "hs38", ["-s", "U", "-l", "0.99"]),
+        ("U_unique", "mmannot_dump", "hs38", ["-s", "U", "-y", "unique"]),
+        ("U_ratio", "mmannot_dump", "hs38", ["-s", "U", "-y", "ratio"]),
+        ("U_random", "mmannot_dump", "hs38", ["-s", "U", "-y", "random"]),
+        ("U_ratio_l0.5", "mmannot_dump", "hs38", ["-s", "U", "-y", "ratio", "-l", "0.5"]),
+        ("U_d0D0", "mmannot_dump", "hs38", ["-s", "U", "-d", "0", "-D", "0"]),
+        ("U_d5000D200", "mmannot_dump", "hs38", ["-s", "U", "-d", "5000", "-D", "200"]),
+        ("pF_default", "mmannot_patched_dump", "hs38", ["-s", "F"]),
+        ("pR_default", "mmannot_patched_dump", "hs38", ["-s", "R"]),
+        ("pF_ratio", "mmannot_patched_dump", "hs38", ["-s", "F", "-y", "ratio"]),
+        ("pF_l5", "mmannot_patched_dump", "hs38", ["-s", "F", "-l", "5"]),
+        ("pR_unique_l0.3", "mmannot_patched_dump", "hs38", ["-s", "R", "-y", "unique", "-l", "0.3"]),
+        ("amb_U_default", "mmannot_dump", "amb", ["-s", "U", "-d", "5000", "-D", "5000"]),
+        ("amb_U_l0.3", "mmannot_dump", "amb", ["-s", "U", "-d", "5000", "-D", "5000", "-l", "0.3"]),
+        ("amb_U_l20", "mmannot_dump", "amb", ["-s", "U", "-d", "5000", "-D", "5000", "-l", "20"]),
+        ("amb_pF_l1", "mmannot_patched_dump", "amb", ["-s", "F", "-d", "5000", "-D", "5000", "-l", "1"]),
+        ("amb_pR_ratio", "mmannot_patched_dump", "amb", ["-s", "R", "-d", "5000", "-D", "5000", "-y", "ratio"]),
+    ]
+    meta = {}
+    hitmasks = {}
+    index_written = {}
+    reads_saved = False
+    for name, variant, ck, extra in cases:
+        dump = os.path.join(tmp, name + ".dump")
+        tsv = os.path.join(tmp, name + ".tsv")
+        rc, so, se = mo.run_ref(variant, ["-a", gtf, "-r", bam, "-c", configs[ck], "-o", tsv] + extra, dump=dump)
+        assert rc == 0, (name, se)
+        iv, hits = mo.parse_dump(dump)
+        # index fixture per (config, -d, -D)
+        d = extra[extra.index("-d") + 1] if "-d" in extra else "1000"
+        D = extra[extra.index("-D") + 1] if "-D" in extra else "1000"
+        ikey = f"{ck}_d{d}_D{D}"
+        if ikey not in index_written:
+            write_iv_dump(iv, os.path.join(out, f"index_{ikey}.tsv.gz"))
+            index_written[ikey] = True
+        # true record strands come from the patched -s F dump (strandF(record.strand) = record.strand)
+        if name == "pF_default" and not reads_saved:
+            chr_names = []
+            for c, nm in zip(iv["chr"], iv["chr_name"]):
+                while len(chr_names) <= c:
+                    chr_names.append(None)
+                chr_names[c] = nm
+            cmap = {nm: i for i, nm in enumerate(chr_names)}
+            qid = mo.names_to_qid(hits["name"])
+            np.savez_compressed(os.path.join(out, "reads.npz"),
+                                tid=np.array([cmap.get(c, -1) for c in hits["chr_name"]], dtype=np.int32),
+                                start=np.array(hits["start"], dtype=np.int64), end=np.array(hits["end"], dtype=np.int64),
+                                strand=np.array(hits["strand"], dtype=np.uint8), nh=np.array(hits["nh"], dtype=np.uint32),
+                                qid=qid.astype(np.int64))
+            json.dump({"chromosomes": chr_names}, open(os.path.join(out, "chromosomes.json"), "w"))
+            reads_saved = True
+        hitmasks[name] = np.array(hits["mask"], dtype=np.uint64)
+        meta[name] = dict(variant=variant, config=ck, index=ikey, args=extra, table=open(tsv).read(),
+                          stderr=se.replace(REF, "$REF"), n_hit_lines=len(hits["mask"]))
+        print(name, "rows", meta[name]["table"].count("\n") - 1, file=sys.stderr)
+    # reference failure modes that the CLI must reproduce
+    rc, so, se = mo.run_ref("mmannot", ["-a", gtf, "-r", bam, "-c", os.path.join(REF, "configTest.txt"), "-s", "U"])
+    meta["fail_configTest"] = dict(rc=rc, stderr=se.replace(REF, "$REF"), stdout=so)
+    rc, so, se = mo.run_ref("mmannot", ["-a", gtf, "-r", bam, "-c", configs["hs38"], "-s", "FR"])
+    meta["fail_sFR"] = dict(rc=rc, stderr=se.replace(REF, "$REF"), stdout=so)
+    json.dump(meta, open(os.path.join(out, "cases.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(out, "hitmasks.npz"), **hitmasks)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["test_dataset"]
+    if not mo.have_ref():
+        sys.exit("oracle/_ref not built (run oracle/build_ref.sh in the build container)")
+    if "test_dataset" in what:
+        gen_test_dataset()
+    if "kat" in what:
+        from oracle import gen_kat
+        gen_kat.main()
+    if "synth" in what:
+        from oracle import gen_synth_golden
+        gen_synth_golden.main()
