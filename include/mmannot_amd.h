@@ -1,0 +1,170 @@
+/*
+ * mmannot_amd.h — C ABI of the MI355X-native overlap-and-count engine.
+ *
+ * Drop-in boundary for the hot path of mzytnicki/mmannot v1.1 (all citations are into the
+ * reference's single translation unit, mmannot.cpp).  The reference has no plugin / FFI
+ * surface; the seam this library sits behind is the pair of member calls made once per
+ * alignment by Counter::read (mmannot.cpp:1767-1782):
+ *
+ *     IntervalList::scan(Read&, vector<size_t>& regions, ...)      mmannot.cpp:1291-1332
+ *     Counter::addCount(name, regions, intervals, nHits)           mmannot.cpp:1665-1739
+ *
+ * plus the end-of-file flush (mmannot.cpp:1783-1792), Counter::getCounts()/dump()
+ * (mmannot.cpp:1803-1818) and TableCount (mmannot.cpp:1854-1901).  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature (a hipStream_t is
+ * passed as void*).  All functions return MM_OK (0) or an MM_ERR_* code; mm_last_error()
+ * gives the message of the last failure on the calling thread.
+ *
+ * The device path is the only path: every compute entry point fails with MM_ERR_HIP when
+ * no gfx950 device/runtime is usable.  There is no CPU fallback.
+ */
+#ifndef MMANNOT_AMD_H
+#define MMANNOT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_VERSION "mmannot-amd 0.1 (drop-in for mmannot v1.1)"
+#define MM_MAX_ELEMENTS 64 /* an element set travels as a 64-bit mask */
+
+enum {
+  MM_OK = 0,
+  MM_ERR_ARG = 1,        /* bad argument                                             */
+  MM_ERR_HIP = 2,        /* HIP runtime / device failure (incl. no device)           */
+  MM_ERR_RANGE = 3,      /* value outside the supported domain (E > 64, coord >= 2^31) */
+  MM_ERR_TABLE_FULL = 4, /* more distinct element sets than the device table holds   */
+  MM_ERR_NOMEM = 5,
+  MM_ERR_STATE = 6,      /* call out of order (e.g. annotate after finalize)         */
+  MM_ERR_IO = 7,
+  MM_ERR_PARSE = 8
+};
+
+/* Strand of an Order element / of an annotation interval: enum class Strand, mmannot.cpp:49 */
+enum { MM_STRAND_ALL = 0, MM_STRAND_F = 1, MM_STRAND_R = 2 };
+/* Which intervalOverlapFunction -l selects, mmannot.cpp:992-1002, 1972-1977 */
+enum { MM_OVL_INCLUSION = 0, MM_OVL_PC = 1, MM_OVL_NT = 2 };
+/* -s U/F/R -> strandU/strandF/strandR, mmannot.cpp:836-844, 1981-1983 */
+enum { MM_STRANDED_U = 0, MM_STRANDED_F = 1, MM_STRANDED_R = 2 };
+/* -y, enum class Strategy mmannot.cpp:50, 2036-2039 */
+enum { MM_STRAT_DEFAULT = 0, MM_STRAT_UNIQUE = 1, MM_STRAT_RANDOM = 2, MM_STRAT_RATIO = 3 };
+/* Counter's seven counters in declaration order, mmannot.cpp:1663 */
+enum { MM_STAT_HITS = 0, MM_STAT_READS, MM_STAT_UNIQUE, MM_STAT_AMBIGUOUS, MM_STAT_MULTIPLE, MM_STAT_UNASSIGNED, MM_STAT_RESCUED, MM_N_STATS };
+
+/* The flattened Order section: what scan/getFirst/checkStrand need from Config
+ * (mmannot.cpp:222-226, 370-374, 438-443, 463-470). */
+typedef struct mm_elements {
+  int32_t n_elements;         /* Config::getNElements()                         */
+  const int32_t *line_of;     /* [E] Order line of element e (RegionType.id)    */
+  const uint8_t *elem_strand; /* [E] MM_STRAND_* of the Order entry             */
+  const uint8_t *is_up;       /* [E] entry's type is "upstream"                 */
+  const uint8_t *is_down;     /* [E] entry's type is "downstream"               */
+} mm_elements;
+
+/* namespace Globals, mmannot.cpp:69-90 — the part the hot path reads */
+typedef struct mm_options {
+  int32_t overlap_mode;   /* MM_OVL_*                                  */
+  float overlap_value;    /* Globals::overlap (float)                  */
+  int32_t strandedness;   /* MM_STRANDED_*                             */
+  int32_t strategy;       /* MM_STRAT_* (RANDOM is host-side only: MM_ERR_ARG here) */
+  int32_t keep_hit_masks; /* debug/parity: keep the per-hit region sets of the last batch */
+} mm_options;
+
+/* One Read as handed to scan() (class Read, mmannot.cpp:846-903), 16 bytes.
+ *   start = record.start = pos0+1 (mmannot.cpp:1537), end after parseCigar (mmannot.cpp:852-875,
+ *   may be start-1 for a record without CIGAR operations).
+ *   tid_strand bit 0  = record.strand (1 when flag 0x10 is clear, mmannot.cpp:608)
+ *              bits 31..1 = index into the *annotation's* chromosome table + 1; 0 = the read's
+ *              chromosome is unknown to the annotation (mmannot.cpp:1293-1302).
+ *   qid = dense id of the read name (the reference keys readCounts on the string, mmannot.cpp:1671).
+ * NH (record.nHits, mmannot.cpp:1560, 1637-1641) travels in a parallel uint32 array; NULL = all 1. */
+typedef struct mm_aln {
+  int32_t start;
+  int32_t end;
+  uint32_t tid_strand;
+  uint32_t qid;
+} mm_aln;
+#define MM_ALN_TID_STRAND(tid, strand_plus) ((((uint32_t) ((tid) + 1)) << 1) | ((strand_plus) ? 1u : 0u))
+
+typedef struct mm_index mm_index; /* IntervalList's index members, mmannot.cpp:1086-1090, resident in HBM */
+typedef struct mm_ctx mm_ctx;     /* one Counter (mmannot.cpp:1653-1664) on one GPU                      */
+
+const char *mm_last_error(void);
+const char *mm_version(void);
+
+/* ---- index: replaces the sorted TypedInterval vector + bins of IntervalList (mmannot.cpp:1267-1284).
+ * Input = the interval vector *after* the reference's std::sort (order is significant:
+ * EvaluationStructure::set is last-writer-wins, mmannot.cpp:1023-1028), chr ascending.
+ * bin_shift: log2 of the device bin width, 0 = choose automatically. */
+int mm_index_create(mm_index **out, const mm_elements *elems, int32_t n_chromosomes, size_t n_intervals,
+                    const int32_t *chr, const int32_t *start, const int32_t *end, const uint8_t *type,
+                    const uint8_t *strand, int device, int bin_shift);
+void mm_index_destroy(mm_index *ix);
+/* sizes of the device structures (bytes): [0]=interval records [1]=bin table [2]=active lists, [3]=bin shift */
+int mm_index_info(const mm_index *ix, uint64_t info[4]);
+
+/* ---- context: replaces Counter (clear/read/getCounts/dump). stream: hipStream_t or NULL (a private stream). */
+int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options *opt, void *stream);
+void mm_ctx_destroy(mm_ctx *ctx);
+/* Counter::clear(), mmannot.cpp:1742-1747 */
+int mm_reset(mm_ctx *ctx);
+
+/* One batch of the per-alignment loop of Counter::read (mmannot.cpp:1772-1781): for every tuple,
+ * scan() then addCount().  Asynchronous on the context's stream.
+ *   on_device = 0: aln/nh are host buffers (pinned for overlap), copied with hipMemcpyAsync; they must
+ *                  stay valid until mm_sync().
+ *   on_device = 1: aln/nh are device pointers (inputs already resident in HBM).
+ *   qid_bound: exclusive upper bound of every qid seen so far including this batch (sizes the
+ *              per-read-name state of -y default; ignored by the other strategies).
+ * Batches must be submitted in file order (the multi-hit countdown is order dependent, mmannot.cpp:1669-1701). */
+int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, const uint32_t *nh, size_t n, uint64_t qid_bound, int on_device);
+int mm_sync(mm_ctx *ctx);
+/* End of input: the flush of still-pending multi-hit reads, mmannot.cpp:1783-1792. Synchronises. */
+int mm_finalize(mm_ctx *ctx);
+
+/* Counter's counters (valid after mm_sync / mm_finalize). */
+int mm_get_stats(mm_ctx *ctx, uint64_t stats[MM_N_STATS]);
+/* Counter::getCounts(), mmannot.cpp:1803: one row per distinct element set, unsorted.
+ * sums[] is the reference's double accumulator (exactly integral except under -y ratio). */
+int mm_get_rows(mm_ctx *ctx, uint64_t *masks, double *sums, size_t cap, size_t *n_rows);
+/* Parity/debug: region set of every tuple of the last batch (requires keep_hit_masks);
+ * ~0 marks a tuple skipped by -y unique (mmannot.cpp:1773). */
+int mm_get_hit_masks(mm_ctx *ctx, uint64_t *out, size_t n);
+/* Average number of candidate records visited per alignment in the last batch (profiling aid; requires keep_hit_masks). */
+int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
+
+/* Live timing with HIP events recorded on the context's stream around each phase of
+ * mm_annotate_batch / mm_finalize (bench.py's roofline leg).  Off by default. */
+enum { MM_PHASE_H2D = 0, MM_PHASE_PROBE, MM_PHASE_COMPACT, MM_PHASE_SORT, MM_PHASE_MERGE, MM_PHASE_FLUSH, MM_N_PHASES };
+int mm_set_profiling(mm_ctx *ctx, int on);
+/* synchronises; ms[p] = summed duration of phase p since mm_set_profiling(ctx,1), launches[p] = how many spans */
+int mm_get_phase_ms(mm_ctx *ctx, double ms[MM_N_PHASES], uint64_t launches[MM_N_PHASES]);
+
+/* ---- host finalisation (pure host code, no device): TableCount, mmannot.cpp:1854-1901 */
+/* `unsigned int v = round(double)` as the reference's x86-64 build evaluates it, mmannot.cpp:1868 */
+uint32_t mm_round_to_uint(double v);
+/* std::sort over the vector<size_t> keys, mmannot.cpp:1883: sorts rows in place */
+void mm_sort_rows(uint64_t *masks, double *sums, size_t n_rows);
+
+/* ---- synthetic workload generators for bench.py / tests (device kernels, counter-based RNG;
+ * tests/synth_ref.py holds the numpy twin).  See DESIGN.md "Synthetic inputs". */
+typedef struct mm_synth_params {
+  uint64_t seed;
+  uint64_t first;          /* index of the first alignment of this batch in the stream        */
+  int32_t read_len;        /* every read is <read_len>M                                        */
+  int32_t nh_max;          /* 1: every read NH=1; k>1: groups with NH = 1..k, exactly NH hits  */
+  int32_t n_chromosomes;
+  const int64_t *chr_len;  /* host array [n_chromosomes]                                       */
+  uint32_t scatter_log2;   /* hits of one read are spread over windows of 2^scatter_log2 tuples */
+} mm_synth_params;
+int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_params *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMANNOT_AMD_H */

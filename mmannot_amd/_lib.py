@@ -1,0 +1,94 @@
+"""ctypes binding of include/mmannot_amd.h.
+
+torch is imported first on purpose: PyTorch-ROCm ships its own libamdhip64.so (SONAME
+libamdhip64.so.7); loading it before libmmannot_amd.so makes both share ONE HIP runtime in the
+process, so device pointers and streams created by torch are valid inside the library.
+
+There is no fallback: if the shared library is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+try:  # plumbing only (device memory, streams, torch.distributed)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch-less use of the C ABI is allowed
+    torch = None
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmmannot_amd.so")
+
+MM_N_STATS = 7
+STAT_NAMES = ("nHits", "nReads", "nUnique", "nAmbiguous", "nMultiple", "nUnassigned", "nRescued")
+
+
+class MMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mmannot_amd error {code}: {msg}")
+        self.code = code
+
+
+class Elements(C.Structure):
+    _fields_ = [("n_elements", C.c_int32), ("line_of", C.c_void_p), ("elem_strand", C.c_void_p),
+                ("is_up", C.c_void_p), ("is_down", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("overlap_mode", C.c_int32), ("overlap_value", C.c_float), ("strandedness", C.c_int32),
+                ("strategy", C.c_int32), ("keep_hit_masks", C.c_int32)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first", C.c_uint64), ("read_len", C.c_int32), ("nh_max", C.c_int32),
+                ("n_chromosomes", C.c_int32), ("chr_len", C.c_void_p), ("scatter_log2", C.c_uint32)]
+
+
+_lib = None
+
+# every symbol include/mmannot_amd.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = {
+    "mm_last_error": (C.c_char_p, []),
+    "mm_version": (C.c_char_p, []),
+    "mm_index_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Elements), C.c_int32, C.c_size_t, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "mm_index_destroy": (None, [C.c_void_p]),
+    "mm_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Options), C.c_void_p]),
+    "mm_ctx_destroy": (None, [C.c_void_p]),
+    "mm_reset": (C.c_int, [C.c_void_p]),
+    "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int]),
+    "mm_sync": (C.c_int, [C.c_void_p]),
+    "mm_finalize": (C.c_int, [C.c_void_p]),
+    "mm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_get_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mm_get_hit_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "mm_round_to_uint": (C.c_uint32, [C.c_double]),
+    "mm_sort_rows": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mm_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(SynthParams), C.c_void_p]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m mmannot_amd.build` "
+                              "(the HIP library is the only implementation of the hot path; there is no fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            if not hasattr(l, name):
+                continue  # optional groups are bound lazily below
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MMError(rc, lib().mm_last_error().decode(errors="replace"))

@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference's interface for the overlap-and-count path.
+
+Same names and argument meaning as the classes of mmannot.cpp so that the parity tests read
+like the reference's call sites:
+
+    Config         mmannot.cpp:219-471   (the flattened Order: elements, names, strands)
+    IntervalIndex  IntervalList          mmannot.cpp:1084-1336 (device-resident index; scan() lives in the kernel)
+    Counter        Counter               mmannot.cpp:1653-1852 (clear / read -> add_batch+flush / getCounts / dump)
+    TableCount     TableCount            mmannot.cpp:1854-1901 (addCounter / dump)
+
+Everything heavy happens behind the C ABI (include/mmannot_amd.h) on the GPU; this module holds
+no compute and has no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import Elements, Options, check, lib
+
+STRAND_ALL, STRAND_F, STRAND_R = 0, 1, 2
+OVL_INCLUSION, OVL_PC, OVL_NT = 0, 1, 2
+STRANDEDNESS = {"U": 0, "F": 1, "R": 2}
+STRATEGY = {"default": 0, "unique": 1, "random": 2, "ratio": 3}
+
+ALN_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("tid_strand", "<u4"), ("qid", "<u4")])
+
+
+def pack_alignments(tid, start, end, strand, qid) -> np.ndarray:
+    """SoA -> the 16-byte mm_aln tuples (include/mmannot_amd.h). tid < 0 = chromosome unknown to the annotation."""
+    n = len(start)
+    a = np.empty(n, dtype=ALN_DTYPE)
+    a["start"] = start
+    a["end"] = end
+    a["tid_strand"] = ((np.asarray(tid, dtype=np.int64) + 1).astype(np.uint32) << np.uint32(1)) | (np.asarray(strand, dtype=np.uint32) & np.uint32(1))
+    a["qid"] = np.asarray(qid, dtype=np.uint32)
+    return a
+
+
+def overlap_mode_of(l: float) -> int:
+    """-l: <0 inclusion, <1 fraction of the read, else nucleotides (mmannot.cpp:1972-1977)."""
+    l = np.float32(l)
+    if l < 0.0:
+        return OVL_INCLUSION
+    if l < 1.0:
+        return OVL_PC
+    return OVL_NT
+
+
+@dataclass
+class ConfigElement:
+    source: str
+    type: str
+    strand: int
+    line: int
+
+
+class Config:
+    """The part of Config (mmannot.cpp:219-471) the hot path uses: the flattened Order."""
+
+    def __init__(self, elements: Sequence[ConfigElement]):
+        self.elements = list(elements)
+        if not (1 <= len(self.elements) <= 64):
+            raise ValueError("1..64 Order elements are supported on the device (element sets travel as 64-bit masks)")
+
+    @staticmethod
+    def from_json(js) -> "Config":
+        return Config([ConfigElement(d["source"], d["type"], int(d["strand"]), int(d["line"])) for d in js])
+
+    def getNElements(self) -> int:
+        return len(self.elements)
+
+    def getName(self, i: int) -> str:  # mmannot.cpp:445-462
+        e = self.elements[i]
+        s = e.source
+        if e.type:
+            s += ":" + e.type
+        if e.strand == STRAND_F:
+            s += " (+)"
+        elif e.strand == STRAND_R:
+            s += " (-)"
+        return s
+
+    def isUpstream(self, i: int) -> bool:  # mmannot.cpp:463-466
+        return self.elements[i].type == "upstream"
+
+    def isDownstream(self, i: int) -> bool:  # mmannot.cpp:467-470
+        return self.elements[i].type == "downstream"
+
+    def _c_elements(self):
+        E = len(self.elements)
+        self._line = np.array([e.line for e in self.elements], dtype=np.int32)
+        self._strand = np.array([e.strand for e in self.elements], dtype=np.uint8)
+        self._up = np.array([self.isUpstream(i) for i in range(E)], dtype=np.uint8)
+        self._down = np.array([self.isDownstream(i) for i in range(E)], dtype=np.uint8)
+        return Elements(E, self._line.ctypes.data, self._strand.ctypes.data, self._up.ctypes.data, self._down.ctypes.data)
+
+
+class IntervalIndex:
+    """IntervalList's sorted interval vector + bins (mmannot.cpp:1086-1090, 1267-1284) resident in HBM."""
+
+    def __init__(self, config: Config, chr, start, end, type, strand, n_chromosomes: int, device: int = 0, bin_shift: int = 0):
+        self.config = config
+        self.n_chromosomes = int(n_chromosomes)
+        chr_ = np.ascontiguousarray(chr, dtype=np.int32)
+        st = np.ascontiguousarray(start, dtype=np.int64)
+        en = np.ascontiguousarray(end, dtype=np.int64)
+        if len(st) and (st.max() >= 2**31 - 16 or en.max() >= 2**31 - 16 or st.min() < 0):
+            raise ValueError("coordinates must be in [0, 2^31)")
+        st32 = st.astype(np.int32)
+        en32 = en.astype(np.int32)
+        ty = np.ascontiguousarray(type, dtype=np.uint8)
+        sd = np.ascontiguousarray(strand, dtype=np.uint8)
+        self.n_intervals = len(st32)
+        h = C.c_void_p()
+        el = config._c_elements()
+        check(lib().mm_index_create(C.byref(h), C.byref(el), self.n_chromosomes, self.n_intervals, chr_.ctypes.data,
+                                    st32.ctypes.data, en32.ctypes.data, ty.ctypes.data, sd.ctypes.data, device, bin_shift))
+        self._h = h
+        self.device = device
+
+    def info(self) -> Dict[str, int]:
+        a = (C.c_uint64 * 4)()
+        check(lib().mm_index_info(self._h, a))
+        return dict(interval_bytes=a[0], bin_bytes=a[1], active_bytes=a[2], bin_shift=a[3])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Counter:
+    """Counter (mmannot.cpp:1653-1852) on one GPU."""
+
+    def __init__(self, index: IntervalIndex, *, overlap: float = -1.0, strandedness: str = "F", strategy: str = "default",
+                 keep_hit_masks: bool = False, stream: Optional[int] = None):
+        self.index = index
+        self.strategy = strategy
+        opt = Options(overlap_mode_of(overlap), float(np.float32(overlap)), STRANDEDNESS[strandedness], STRATEGY[strategy],
+                      1 if keep_hit_masks else 0)
+        h = C.c_void_p()
+        check(lib().mm_ctx_create(C.byref(h), index._h, C.byref(opt), C.c_void_p(stream) if stream else None))
+        self._h = h
+        self._keep = []  # host buffers that must outlive the async copy
+
+    def clear(self):  # Counter::clear mmannot.cpp:1742-1747
+        check(lib().mm_reset(self._h))
+
+    def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int):
+        """Host tuples (mm_aln structured array) -> one batch of the loop of Counter::read (mmannot.cpp:1772-1781)."""
+        aln = np.ascontiguousarray(aln)
+        assert aln.dtype == ALN_DTYPE
+        nhp = None
+        if nh is not None:
+            nh = np.ascontiguousarray(nh, dtype=np.uint32)
+            nhp = nh.ctypes.data
+        self._keep.append((aln, nh))
+        check(lib().mm_annotate_batch(self._h, aln.ctypes.data, nhp, len(aln), int(qid_bound), 0))
+
+    def add_batch_device(self, aln_ptr: int, nh_ptr: Optional[int], n: int, qid_bound: int):
+        """Tuples already resident in HBM (e.g. torch tensors: pass .data_ptr())."""
+        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), C.c_void_p(nh_ptr) if nh_ptr else None, int(n), int(qid_bound), 1))
+
+    def sync(self):
+        check(lib().mm_sync(self._h))
+        self._keep.clear()
+
+    def flush(self):
+        """End of file: pending multi-hit reads are counted (mmannot.cpp:1783-1792)."""
+        check(lib().mm_finalize(self._h))
+        self._keep.clear()
+
+    def stats(self) -> Dict[str, int]:
+        a = (C.c_uint64 * _lib.MM_N_STATS)()
+        check(lib().mm_get_stats(self._h, a))
+        return {nm: int(a[i]) for i, nm in enumerate(_lib.STAT_NAMES)}
+
+    def getCounts(self):
+        """Counter::getCounts mmannot.cpp:1803: (masks, sums) unsorted."""
+        n = C.c_size_t(0)
+        check(lib().mm_get_rows(self._h, None, None, 0, C.byref(n)))
+        masks = np.zeros(max(1, n.value), dtype=np.uint64)
+        sums = np.zeros(max(1, n.value), dtype=np.float64)
+        check(lib().mm_get_rows(self._h, masks.ctypes.data, sums.ctypes.data, len(masks), C.byref(n)))
+        return masks[:n.value], sums[:n.value]
+
+    def hit_masks(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint64)
+        check(lib().mm_get_hit_masks(self._h, out.ctypes.data, n))
+        return out
+
+    def walk_stats(self):
+        a = (C.c_uint64 * 2)()
+        check(lib().mm_get_walk_stats(self._h, a))
+        return int(a[0])
+
+    PHASES = ("h2d", "probe", "compact", "sort", "merge", "flush")
+
+    def set_profiling(self, on: bool):
+        check(lib().mm_set_profiling(self._h, 1 if on else 0))
+
+    def phase_ms(self):
+        ms = (C.c_double * 6)()
+        nl = (C.c_uint64 * 6)()
+        check(lib().mm_get_phase_ms(self._h, ms, nl))
+        return {p: (float(ms[i]), int(nl[i])) for i, p in enumerate(self.PHASES)}
+
+    def dump(self, file_name: str) -> str:
+        """Counter::dump mmannot.cpp:1806-1818 (the text the reference writes to stderr)."""
+        return format_stats(self.stats(), file_name)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TableCount:
+    """TableCount (mmannot.cpp:1854-1901): one column per input file."""
+
+    def __init__(self, config: Config, n_inputs: int = 1):
+        self.config = config
+        self.n_inputs = n_inputs
+        self.n_columns = 0
+        self.rows: Dict[int, List[int]] = {}
+
+    def addCounter(self, counter: Counter):  # mmannot.cpp:1861-1876
+        masks, sums = counter.getCounts()
+        self.add_rows(masks, sums)
+
+    def add_rows(self, masks, sums):
+        for m, s in zip(masks, sums):
+            col = self.rows.setdefault(int(m), [0] * self.n_inputs)
+            col[self.n_columns] = int(lib().mm_round_to_uint(float(s)))
+        self.n_columns += 1
+
+    def sorted_masks(self) -> np.ndarray:
+        m = np.array(sorted(self.rows.keys()), dtype=np.uint64)
+        if len(m):
+            lib().mm_sort_rows(m.ctypes.data, None, len(m))
+        return m
+
+    def dump(self, samples: Sequence[str]) -> str:  # mmannot.cpp:1877-1900
+        out = ["Type" + "".join("\t" + s for s in samples)]
+        for m in self.sorted_masks():
+            name = "--".join(self.config.getName(i) for i in range(64) if (int(m) >> i) & 1)
+            out.append(name + "".join("\t" + str(v) for v in self.rows[int(m)]))
+        return "\n".join(out) + "\n"
+
+
+def format_stats(stats: Dict[str, int], file_name: str) -> str:
+    """Counter::dump + printStats (mmannot.cpp:139-143, 1806-1818) under the comma_numpunct locale (:111-115)."""
+    out = [f"Results for {file_name}:"]
+    if stats["nHits"] == 0:
+        out.append("\tNo hit.")
+        return "\n".join(out) + "\n"
+
+    def ps(n: int, s: str, tot: int) -> str:
+        size = int(np.log10(float(tot))) + 1 if tot > 0 else 0
+        size += int(size / 3.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pc = np.float32(n) / np.float32(tot) * np.float32(100)
+        return "\t" + s + f"{n:,}".rjust(size) + " (" + ("%.1f" % float(pc)).rjust(5) + "%)"
+
+    out.append("\t# reads:                       " + f"{stats['nReads']:,}")
+    out.append(ps(stats["nUnique"], "# uniquely mapped reads:       ", stats["nReads"]))
+    out.append(ps(stats["nRescued"], "# multi-mapping rescued reads: ", stats["nReads"]))
+    out.append("\t# hits:                        " + f"{stats['nHits']:,}")
+    out.append(ps(stats["nAmbiguous"], "# ambiguous hits:              ", stats["nHits"]))
+    out.append(ps(stats["nUnassigned"], "# unassigned hits:             ", stats["nHits"]))
+    return "\n".join(out) + "\n"

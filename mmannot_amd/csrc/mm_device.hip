@@ -1,0 +1,1150 @@
+// mm_device.hip — gfx950 (MI355X) device path of the overlap-and-count engine + its C ABI.
+//
+// Reference behaviour (mzytnicki/mmannot v1.1, mmannot.cpp):
+//   IntervalList::scan            :1291-1332   -> k_probe (candidate enumeration + strand + -l filter)
+//   EvaluationStructure::getFirst :1029-1076   -> priority selection inside k_probe
+//   Counter::addCount             :1665-1739   -> k_probe (per-hit branch), k_chunk_default (multi-hit
+//                                                 countdown / union), k_ratio_accum (-y ratio)
+//   Counter::read flush           :1783-1792   -> k_flush_pending
+//   Counter::getCounts / dump     :1803-1818   -> mm_get_rows / mm_get_stats
+//
+// This is not a translation of the reference's walk.  The reference sorts intervals by start,
+// jumps through a 16 kb bin table keyed on interval *ends* and walks forward; long intervals
+// make that walk long and lane-divergent.  Here the index is a "checkpointed sweep":
+//   bins[b]   = { first interval whose start >= b*W ,  offset of bin b's active list }
+//   act[...]  = copies of the interval records that are open at b*W (start < b*W <= end+1),
+//               in index order
+// so the candidates of a read starting in bin b are exactly  act(b) ++ iv[first(b) .. start<=read.end],
+// visited in the reference's index order (which matters: EvaluationStructure::set is last-writer-wins).
+// See DESIGN.md for the equivalence argument, including the "leading isBefore run" quirk.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mmannot_amd.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ----------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(MM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+extern "C" const char *mm_last_error(void) { return g_err.c_str(); }
+extern "C" const char *mm_version(void) { return MM_VERSION; }
+
+// ----------------------------------------------------------------------------- device structures
+#define GT_CAP (1u << 16)          // global element-set table (distinct rows of the count table)
+#define LT_CAP 256u                // per-workgroup LDS table
+#define NO_KEY 0xFFFFFFFFu
+
+struct GlobalTable {
+  u64 *key;      // 0 = empty (an element set is never empty)
+  u64 *cnt;      // integer count (default / unique)
+  double *sum;   // -y ratio accumulator (file-order double adds, mmannot.cpp:1730)
+  u32 *err;      // set to 1 when the table is full
+};
+
+struct ProbeParams {
+  const int4 *iv;          // {start, end, type | F<<8, exclusive prefix max of end within the chromosome}
+  const int4 *act;         // same record format
+  const uint2 *bins;       // per chromosome nbins+1 entries {first, actOff}
+  const u32 *chrBinBase;
+  const u32 *chrNBins;
+  const u32 *chrIvEnd;
+  u32 nchr;
+  u32 shift;
+  u64 elemF, elemR, elemUp, elemDown;  // bit e set: element e is declared '+', '-', is "upstream", is "downstream"
+  int overlapMode;
+  float overlapValue;
+  int strandedness;
+  int strategy;
+  int keep;
+  u64 lineMask[64];        // lineMask[e] = elements on the same Order line as e
+};
+
+__device__ __forceinline__ u32 hash64(u64 k) {
+  k *= 0x9E3779B97F4A7C15ull;
+  return (u32) (k >> 40);
+}
+
+struct LdsTable {
+  u64 key[LT_CAP];
+  u32 cnt[LT_CAP];
+};
+
+__device__ __forceinline__ void lds_table_init(LdsTable &t) {
+  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; }
+}
+
+__device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
+  u32 h = hash64(m) & (LT_CAP - 1);
+  for (u32 p = 0; p < LT_CAP; ++p) {
+    u64 k = *(volatile u64 *) &t.key[h];
+    if (k == 0) {
+      k = atomicCAS(&t.key[h], 0ull, m);
+      if (k == 0) k = m;
+    }
+    if (k == m) { atomicAdd(&t.cnt[h], inc); return true; }
+    h = (h + 1) & (LT_CAP - 1);
+  }
+  return false;
+}
+
+// returns slot or NO_KEY when full (error flag raised)
+__device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
+  u32 h = hash64(m) & (GT_CAP - 1);
+  for (u32 p = 0; p < GT_CAP; ++p) {
+    u64 k = *(volatile u64 *) &g.key[h];
+    if (k == 0) {
+      k = atomicCAS(&g.key[h], 0ull, m);
+      if (k == 0) k = m;
+    }
+    if (k == m) return h;
+    h = (h + 1) & (GT_CAP - 1);
+  }
+  atomicExch(g.err, 1u);
+  return NO_KEY;
+}
+
+__device__ __forceinline__ void gt_add(const GlobalTable &g, u64 m, u64 inc) {
+  u32 s = gt_find_or_insert(g, m);
+  if (s != NO_KEY) atomicAdd(&g.cnt[s], inc);
+}
+
+__device__ __forceinline__ void lds_table_flush(LdsTable &t, const GlobalTable &g) {
+  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) {
+    u64 k = t.key[i];
+    if (k) gt_add(g, k, (u64) t.cnt[i]);
+  }
+}
+
+// ----------------------------------------------------------------------------- candidate test
+// checkStrand (mmannot.cpp:438-443) + the selected intervalOverlapFunction (mmannot.cpp:992-1002).
+// r = interval record, [s,e] = read.  o receives the overlap value handed to EvaluationStructure::set.
+template <int OVL>
+__device__ __forceinline__ bool iv_pass(const ProbeParams &P, const int4 r, const int s, const int e, const int rstrand, u32 &o) {
+  const u32 type = (u32) r.z & 0xffu;
+  const int ivF = (r.z >> 8) & 1;
+  const u32 eF = (u32) (P.elemF >> type) & 1u, eR = (u32) (P.elemR >> type) & 1u;
+  bool ok = true;
+  if (eF | eR) {
+    const bool same = (ivF == rstrand);
+    ok = eF ? same : !same;
+  }
+  // An interval that lies before the read (end < read.start) is only ever tested by the reference when
+  // an earlier interval of the chromosome reaches the read: the first loop of scan() swallows the whole
+  // leading isBefore run (mmannot.cpp:1306-1308).  r.w = max end over all earlier intervals of the chromosome.
+  if (r.y < s && r.w < s) ok = false;
+  if (OVL == MM_OVL_INCLUSION) {  // Interval::includes mmannot.cpp:637-639
+    o = 1;
+    return ok && r.x <= s && e <= r.y;
+  }
+  const int lo = max(s, r.x), hi = min(e, r.y);  // Interval::overlaps mmannot.cpp:632-636 (no +1)
+  if (lo >= hi) return false;
+  const u32 ov = (u32) (hi - lo);
+  o = ov;
+  if (OVL == MM_OVL_PC) {  // intervalOverlapPc mmannot.cpp:995-998: float product, float compare
+    const u32 size = (u32) (e - s + 1);
+    const float lhs = __fmul_rn((float) size, P.overlapValue);
+    return ok && (lhs <= (float) ov);
+  }
+  return ok && ((float) ov >= P.overlapValue);  // intervalOverlap mmannot.cpp:999-1002
+}
+
+// Read::getDistance(p), mmannot.cpp:661-665
+__device__ __forceinline__ u32 rd_distance(int s, int e, int p) {
+  if (p < s) return (u32) (s - p);
+  if (p > e) return (u32) (p - e);
+  return 0;
+}
+
+struct Cand {
+  u32 a0, a1;   // active-list range
+  u32 i0, i1;   // sorted-interval range start / chromosome end
+};
+
+__device__ __forceinline__ bool locate(const ProbeParams &P, u32 tid1, int s, Cand &c) {
+  if (tid1 == 0 || tid1 > P.nchr) return false;    // chromosome unknown to the annotation (mmannot.cpp:1293-1302)
+  const u32 ch = tid1 - 1;
+  const u32 nb = P.chrNBins[ch];
+  if (nb == 0) return false;                       // chromosome without any interval: not in `bins` either
+  u32 b = (u32) s >> P.shift;
+  b = min(b, nb - 1);
+  const uint2 *B = P.bins + P.chrBinBase[ch] + b;
+  const uint2 b0 = B[0];
+  c.a0 = b0.y; c.a1 = B[1].y; c.i0 = b0.x; c.i1 = P.chrIvEnd[ch];
+  return true;
+}
+
+// last passing interval of element `t` in index order -> its (overlap, distance): what
+// EvaluationStructure::set leaves in evaluation[t] (mmannot.cpp:1023-1028, 1316-1323)
+template <int OVL>
+__device__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, int rstrand, u32 t, u32 &o_out, u32 &d_out) {
+  const bool up = (P.elemUp >> t) & 1, down = (P.elemDown >> t) & 1;
+  for (u32 k = c.a0; k < c.a1; ++k) {
+    const int4 r = P.act[k];
+    u32 o;
+    if (((u32) r.z & 0xffu) == t && iv_pass<OVL>(P, r, s, e, rstrand, o)) {
+      o_out = o; d_out = up ? rd_distance(s, e, r.y) : (down ? rd_distance(s, e, r.x) : 0u);
+    }
+  }
+  for (u32 i = c.i0; i < c.i1; ++i) {
+    const int4 r = P.iv[i];
+    if (r.x > e) break;
+    u32 o;
+    if (((u32) r.z & 0xffu) == t && iv_pass<OVL>(P, r, s, e, rstrand, o)) {
+      o_out = o; d_out = up ? rd_distance(s, e, r.y) : (down ? rd_distance(s, e, r.x) : 0u);
+    }
+  }
+}
+
+// scan() + getFirst() for one read -> element set
+template <int OVL>
+__device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32 tid1, int rstrand, u32 &walked) {
+  Cand c;
+  if (!locate(P, tid1, s, c)) return 0;
+  u64 hit = 0;
+  for (u32 k = c.a0; k < c.a1; ++k) {
+    const int4 r = P.act[k];
+    u32 o;
+    if (iv_pass<OVL>(P, r, s, e, rstrand, o)) hit |= 1ull << ((u32) r.z & 0xffu);
+    ++walked;
+  }
+  for (u32 i = c.i0; i < c.i1; ++i) {
+    const int4 r = P.iv[i];
+    if (r.x > e) break;                            // isAfter, mmannot.cpp:1311
+    u32 o;
+    if (iv_pass<OVL>(P, r, s, e, rstrand, o)) hit |= 1ull << ((u32) r.z & 0xffu);
+    ++walked;
+  }
+  if (!hit) return 0;
+  // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
+  const int low = __ffsll((long long) hit) - 1;
+  const u64 cand = hit & P.lineMask[low];
+  if ((cand & (cand - 1)) == 0) return cand;
+  // several elements of the winning line were hit: max overlap, then min distance, ties kept
+  u64 sel = 0;
+  u32 maxO = 0, minD = 0;
+  for (u64 cm = cand; cm; cm &= cm - 1) {
+    const u32 t = (u32) (__ffsll((long long) cm) - 1);
+    u32 o = 0, d = 0;
+    last_of_type<OVL>(P, c, s, e, rstrand, t, o, d);
+    if (o > maxO) { maxO = o; minD = d; sel = 1ull << t; }
+    else if (o == maxO) {
+      if (d < minD) { minD = d; sel = 1ull << t; }
+      else if (d == minD) sel |= 1ull << t;
+    }
+  }
+  return sel;
+}
+
+// ----------------------------------------------------------------------------- k_probe
+// One lane per alignment, grid-stride over the batch.  Per alignment: scan+getFirst, the
+// three per-hit counters of addCount (mmannot.cpp:1666-1668), then either
+//   * the per-hit branch (mmannot.cpp:1703-1738): element set counted through a wave-aggregated,
+//     LDS-privatised table (default with NH<=1, unique), or its table slot recorded for the
+//     ordered -y ratio accumulation, or
+//   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
+template <int OVL>
+__global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const u32 *__restrict__ nhp,
+                                               size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, GlobalTable G,
+                                               u64 *__restrict__ stats, u64 *__restrict__ walkstat) {
+  __shared__ LdsTable T;
+  __shared__ u32 sstat[8];
+  lds_table_init(T);
+  if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  u32 cHits = 0, cReads = 0, cUnique = 0, cAmb = 0, cMulti = 0, cUnas = 0;  // wave-uniform
+  u32 walked = 0;
+  const bool grouped_strategy = (P.strategy == MM_STRAT_DEFAULT);
+  const bool ratio = (P.strategy == MM_STRAT_RATIO);
+  for (size_t base = (size_t) blockIdx.x * blockDim.x; base < n; base += (size_t) gridDim.x * blockDim.x) {
+    const size_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    int4 a = make_int4(0, 0, 0, 0);
+    u32 nh = 1;
+    if (valid) {
+      a = aln[i];
+      if (nhp) nh = nhp[i];
+    }
+    const bool processed = valid && !(P.strategy == MM_STRAT_UNIQUE && nh != 1);  // mmannot.cpp:1773
+    u64 mask = 0;
+    if (processed) {
+      const int rec_strand = a.z & 1;
+      const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
+      mask = probe_one<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked);
+    }
+    const int np = __popcll(mask);
+    const bool grouped = processed && grouped_strategy && nh > 1;
+    cHits += __popcll(__ballot(processed));
+    cUnas += __popcll(__ballot(processed && np == 0));
+    cAmb += __popcll(__ballot(processed && np > 1));
+    cUnique += __popcll(__ballot(processed && np == 1 && nh == 1));
+    cMulti += __popcll(__ballot(grouped));
+    cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
+    const bool counted = processed && !grouped && mask != 0;                       // mmannot.cpp:1704
+    u32 key = NO_KEY;
+    if (grouped) key = (u32) a.w;
+    // wave aggregation over equal element sets
+    bool active = counted;
+    u64 bal;
+    while ((bal = __ballot(active)) != 0) {
+      const int leader = __ffsll((long long) bal) - 1;
+      const u64 m = __shfl(mask, leader);
+      const bool same = active && (mask == m);
+      const u64 sb = __ballot(same);
+      if (ratio) {
+        u32 slot = 0;
+        if ((int) lane == leader) slot = gt_find_or_insert(G, m);
+        slot = __shfl(slot, leader);
+        if (same) key = slot;
+      } else if ((int) lane == leader) {
+        const u32 c = (u32) __popcll(sb);
+        if (!lds_table_add(T, m, c)) gt_add(G, m, c);
+      }
+      active = active && !same;
+    }
+    if (valid) {
+      if (gkey) gkey[i] = key;
+      if (hm && (P.keep || grouped)) hm[i] = processed ? mask : ~0ull;
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&sstat[MM_STAT_HITS], cHits); atomicAdd(&sstat[MM_STAT_READS], cReads);
+    atomicAdd(&sstat[MM_STAT_UNIQUE], cUnique); atomicAdd(&sstat[MM_STAT_AMBIGUOUS], cAmb);
+    atomicAdd(&sstat[MM_STAT_MULTIPLE], cMulti); atomicAdd(&sstat[MM_STAT_UNASSIGNED], cUnas);
+  }
+  if (P.keep) {
+    // total candidates visited (profiling aid)
+    u32 w = walked;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+    if (lane == 0) atomicAdd(&walkstat[0], (u64) w);
+  }
+  __syncthreads();
+  if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
+  lds_table_flush(T, G);
+}
+
+// ----------------------------------------------------------------------------- ordered compaction of (key, index) pairs
+#define RS_THREADS 256
+#define RS_ROUNDS 16
+#define RS_TILE (RS_THREADS * RS_ROUNDS)
+
+__global__ __launch_bounds__(RS_THREADS) void k_flag_count(const u32 *__restrict__ gkey, size_t n, u32 *__restrict__ tileCnt) {
+  __shared__ u32 tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  const size_t lo = (size_t) blockIdx.x * RS_TILE;
+  u32 c = 0;
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
+    c += (i < n && gkey[i] != NO_KEY) ? 1u : 0u;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
+  __syncthreads();
+  if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
+}
+
+// exclusive scan of a[0..n) in place by one workgroup; total -> *total
+__global__ __launch_bounds__(1024) void k_scan_single(u32 *__restrict__ a, u32 n, u32 *__restrict__ total) {
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (u32 base = 0; base < n; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < n) ? a[i] : 0;
+    u32 x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if ((int) lane >= off) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 k = 0; k < w; ++k) woff += wsum[k];
+    const u32 c = carry;
+    if (i < n) a[i] = c + woff + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + woff + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict__ gkey, size_t n, const u32 *__restrict__ tileOff,
+                                                           u32 *__restrict__ keys, u32 *__restrict__ vals) {
+  __shared__ u32 wcnt[4];
+  __shared__ u32 run;
+  if (threadIdx.x == 0) run = tileOff[blockIdx.x];
+  __syncthreads();
+  const size_t lo = (size_t) blockIdx.x * RS_TILE;
+  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
+    u32 k = NO_KEY;
+    if (i < n) k = gkey[i];
+    const bool f = (k != NO_KEY);
+    const u64 bal = __ballot(f);
+    const u32 rank = (u32) __popcll(bal & ((1ull << lane) - 1));
+    if (lane == 0) wcnt[w] = (u32) __popcll(bal);
+    __syncthreads();
+    u32 off = run;
+    for (u32 q = 0; q < w; ++q) off += wcnt[q];
+    if (f) { keys[off + rank] = k; vals[off + rank] = (u32) i; }
+    __syncthreads();
+    if (threadIdx.x == 0) run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------- stable LSD radix sort (8-bit digits)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ Mptr, int shift,
+                                                        u32 *__restrict__ hist, u32 nblk) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 M = *Mptr;
+  const size_t lo = (size_t) blockIdx.x * RS_TILE;
+  if (lo < M) {
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
+      if (i < M) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of its row of per-tile counts
+__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal) {
+  __shared__ u32 wsum[4];
+  __shared__ u32 carry;
+  u32 *row = hist + (size_t) blockIdx.x * nblk;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (u32 base = 0; base < nblk; base += 256) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < nblk) ? row[i] : 0;
+    u32 x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if ((int) lane >= off) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 k = 0; k < w; ++k) woff += wsum[k];
+    const u32 c = carry;
+    if (i < nblk) row[i] = c + woff + x - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = c + woff + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal) {
+  __shared__ u32 s[256];
+  s[threadIdx.x] = rowTotal[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 acc = 0;
+    for (int d = 0; d < 256; ++d) { const u32 v = s[d]; s[d] = acc; acc += v; }
+  }
+  __syncthreads();
+  rowTotal[threadIdx.x] = s[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
+                                                           u32 *__restrict__ vout, const u32 *__restrict__ Mptr, int shift,
+                                                           const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
+  __shared__ u32 run[256];      // next output position of digit d for this tile
+  __shared__ u32 wcnt[4][256];  // per-wave digit counts of the current round
+  const u32 M = *Mptr;
+  const size_t lo = (size_t) blockIdx.x * RS_TILE;
+  if (lo >= M) return;
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+  run[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x];
+  wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
+  __syncthreads();
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t i = lo + (size_t) r * RS_THREADS + t;
+    const bool valid = i < M;
+    u32 k = 0, v = 0;
+    if (valid) { k = kin[i]; v = vin[i]; }
+    const u32 d = (k >> shift) & 255u;
+    // lanes of this wave holding the same digit (8 ballots)
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const u64 bb = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bb : ~bb;
+    }
+    const u32 rank = (u32) __popcll(peers & ((1ull << lane) - 1));
+    if (valid && rank == 0) wcnt[w][d] = (u32) __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      u32 pos = run[d] + rank;
+      for (u32 q = 0; q < w; ++q) pos += wcnt[q][d];
+      kout[pos] = k; vout[pos] = v;
+    }
+    __syncthreads();
+    run[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+    wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------- multi-hit countdown / union (-y default, NH > 1)
+// Input: the batch's multi-hit records sorted by read-name id, file order kept inside a name.
+// One lane per name walks that name's records exactly as addCount does (mmannot.cpp:1669-1701):
+// the first record of a group sets remaining = NH-1 (mmannot.cpp:1673), later ones count down and
+// union their element sets; at 0 the group is closed, counted (mmannot.cpp:1688) and erased, so a
+// further record of the same name opens a new group.  State (remaining, union) is carried across
+// batches in grpRem/grpU, the dense replacement of readCounts (mmannot.cpp:1656).
+__global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ skeys, const u32 *__restrict__ svals,
+                                                       const u32 *__restrict__ Mptr, const u32 *__restrict__ nhp,
+                                                       const u64 *__restrict__ hm, u32 *__restrict__ grpRem, u64 *__restrict__ grpU,
+                                                       GlobalTable G, u64 *__restrict__ stats) {
+  __shared__ LdsTable T;
+  __shared__ u32 sOpened, sRescued;
+  lds_table_init(T);
+  if (threadIdx.x == 0) { sOpened = 0; sRescued = 0; }
+  __syncthreads();
+  const u32 M = *Mptr;
+  u32 opened = 0, rescued = 0;
+  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
+    const u32 q = skeys[j];
+    if (j != 0 && skeys[j - 1] == q) continue;
+    u32 rem = grpRem[q];
+    u64 U = grpU[q];
+    for (size_t k = j; k < M && skeys[k] == q; ++k) {
+      const u32 i = svals[k];
+      const u64 m = hm[i];
+      if (rem == 0) {             // no pending group of this name: open one (mmannot.cpp:1672-1677)
+        rem = nhp[i] - 1; U = m; ++opened;
+      } else {                    // mmannot.cpp:1678-1701
+        --rem; U |= m;
+        if (rem == 0) {
+          if (U) {
+            if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
+            if ((U & (U - 1)) == 0) ++rescued;
+          }
+          U = 0;
+        }
+      }
+    }
+    grpRem[q] = rem; grpU[q] = U;
+  }
+  if (opened) atomicAdd(&sOpened, opened);
+  if (rescued) atomicAdd(&sRescued, rescued);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sOpened) atomicAdd(&stats[MM_STAT_READS], (u64) sOpened);   // ++nReads per new group, mmannot.cpp:1675
+    if (sRescued) atomicAdd(&stats[MM_STAT_RESCUED], (u64) sRescued);
+  }
+  lds_table_flush(T, G);
+}
+
+// End-of-file flush of the still-pending groups, mmannot.cpp:1783-1792
+__global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem, u64 *__restrict__ grpU, u64 Q, GlobalTable G,
+                                                       u64 *__restrict__ stats) {
+  __shared__ LdsTable T;
+  __shared__ u32 sRescued;
+  lds_table_init(T);
+  if (threadIdx.x == 0) sRescued = 0;
+  __syncthreads();
+  u32 rescued = 0;
+  for (u64 q = (u64) blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += (u64) gridDim.x * blockDim.x) {
+    if (grpRem[q] != 0) {
+      const u64 U = grpU[q];
+      if (U) {
+        if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
+        if ((U & (U - 1)) == 0) ++rescued;    // rawCounts > 1 always holds for a pending group, mmannot.cpp:1789
+      }
+      grpRem[q] = 0; grpU[q] = 0;
+    }
+  }
+  if (rescued) atomicAdd(&sRescued, rescued);
+  __syncthreads();
+  if (threadIdx.x == 0 && sRescued) atomicAdd(&stats[MM_STAT_RESCUED], (u64) sRescued);
+  lds_table_flush(T, G);
+}
+
+// -y ratio: regionCounts[set] += 1.0/nHits in file order (mmannot.cpp:1730).  Input: (slot, index) pairs
+// sorted by slot, file order kept inside a slot.  One lane per slot replays its adds in order, in IEEE
+// double with correctly rounded division, starting from the sum carried from earlier batches.
+__global__ __launch_bounds__(256) void k_ratio_accum(const u32 *__restrict__ skeys, const u32 *__restrict__ svals,
+                                                     const u32 *__restrict__ Mptr, const u32 *__restrict__ nhp, GlobalTable G) {
+  const u32 M = *Mptr;
+  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
+    const u32 slot = skeys[j];
+    if (j != 0 && skeys[j - 1] == slot) continue;
+    double S = G.sum[slot];
+    for (size_t k = j; k < M && skeys[k] == slot; ++k) {
+      const u32 nh = nhp ? nhp[svals[k]] : 1u;
+      S = __dadd_rn(S, __ddiv_rn(1.0, (double) nh));
+    }
+    G.sum[slot] = S;
+  }
+}
+
+// ----------------------------------------------------------------------------- synthetic workload (bench / tests)
+struct SynthDev {
+  u64 seed, first;
+  int read_len, nh_max, nchr;
+  u32 scatter_log2;
+  u64 cum[65];   // cumulative chromosome lengths
+};
+
+__host__ __device__ inline u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  u64 z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restrict__ aln, u32 *__restrict__ nhp, size_t n) {
+  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t) gridDim.x * blockDim.x) {
+    const u64 i = S.first + j;
+    // physical index -> logical hit index: affine permutation inside windows of 2^scatter_log2
+    u64 L = i;
+    if (S.scatter_log2) {
+      const u64 W = 1ull << S.scatter_log2;
+      const u64 r = i & (W - 1);
+      L = (i & ~(W - 1)) | ((r * 0x9E3779B1ull + (S.seed & (W - 1))) & (W - 1));
+    }
+    u32 nh = 1;
+    u64 qid = L;
+    if (S.nh_max > 1) {
+      const u64 K = (u64) S.nh_max, T = K * (K + 1) / 2;
+      const u64 blk = L / T, off = L % T;
+      u64 k = (u64) ((sqrt(8.0 * (double) off + 1.0) - 1.0) * 0.5);
+      while (k * (k + 1) / 2 > off) --k;
+      while ((k + 1) * (k + 2) / 2 <= off) ++k;
+      nh = (u32) k + 1;
+      qid = blk * K + k;
+    }
+    const u64 h = splitmix64(S.seed ^ (L * 0xD1342543DE82EF95ull));
+    const u64 h2 = splitmix64(h);
+    const u64 g = h % S.cum[S.nchr];
+    int c = 0;
+    while (g >= S.cum[c + 1]) ++c;
+    const u64 len = S.cum[c + 1] - S.cum[c];
+    const u64 span = len > (u64) S.read_len ? len - (u64) S.read_len + 1 : 1;
+    const u64 pos0 = h2 % span;
+    int4 a;
+    a.x = (int) (pos0 + 1);
+    a.y = a.x + S.read_len - 1;
+    a.z = (int) ((((u32) c + 1u) << 1) | (u32) ((h >> 63) & 1ull));
+    a.w = (int) (u32) qid;
+    aln[j] = a;
+    if (nhp) nhp[j] = nh;
+  }
+}
+
+// ============================================================================= host side
+struct mm_index {
+  int device = 0;
+  int nchr = 0;
+  size_t n_iv = 0, n_act = 0, n_bins = 0;
+  int shift = 0;
+  int E = 0;
+  int4 *d_iv = nullptr, *d_act = nullptr;
+  uint2 *d_bins = nullptr;
+  u32 *d_chrBinBase = nullptr, *d_chrNBins = nullptr, *d_chrIvEnd = nullptr;
+  u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
+  u64 lineMask[64];
+};
+
+struct mm_ctx {
+  const mm_index *ix = nullptr;
+  mm_options opt{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool finalized = false;
+  // batch buffers
+  size_t cap = 0;
+  int4 *d_aln = nullptr;
+  u32 *d_nh = nullptr;
+  u64 *d_hm = nullptr;
+  u32 *d_gkey = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
+  u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr;
+  size_t last_n = 0;
+  // persistent state
+  GlobalTable G{};
+  u64 *d_stats = nullptr, *d_walk = nullptr;
+  u64 qcap = 0;
+  u32 *d_grpRem = nullptr;
+  u64 *d_grpU = nullptr;
+  // optional live timing (HIP events on the context's stream), see mm_set_profiling
+  bool profiling = false;
+  struct Span { int phase; hipEvent_t a, b; };
+  std::vector<Span> spans;
+};
+
+struct PhaseTimer {  // records an event pair around a group of launches when profiling is on
+  mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
+  PhaseTimer(mm_ctx *c_, int ph) : c(c_), phase(ph) {
+    if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void) hipEventRecord(a, c->stream);
+  }
+  void stop() {
+    if (a && b) { (void) hipEventRecord(b, c->stream); c->spans.push_back({phase, a, b}); a = b = nullptr; }
+  }
+  ~PhaseTimer() { stop(); }
+};
+
+static int device_check(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(MM_ERR_HIP, std::string("no HIP device available (") + hipGetErrorString(e) + "); the HIP path is the only path");
+  if (device < 0 || device >= n) return fail(MM_ERR_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  return MM_OK;
+}
+
+extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_chromosomes, size_t n_iv, const int32_t *chr,
+                               const int32_t *start, const int32_t *end, const uint8_t *type, const uint8_t *strand, int device,
+                               int bin_shift) {
+  if (!out || !el || !chr || !start || !end || !type || !strand) return fail(MM_ERR_ARG, "mm_index_create: null argument");
+  *out = nullptr;
+  const int E = el->n_elements;
+  if (E < 1 || E > MM_MAX_ELEMENTS) return fail(MM_ERR_RANGE, "mm_index_create: number of Order elements must be 1..64");
+  if (n_chromosomes < 1) return fail(MM_ERR_ARG, "mm_index_create: no chromosome");
+  if (n_iv == 0) return fail(MM_ERR_ARG, "mm_index_create: empty interval list (the reference exits here, mmannot.cpp:1285-1288)");
+  if (n_iv >= 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_index_create: too many intervals");
+  int rc = device_check(device);
+  if (rc) return rc;
+  mm_index *ix = new mm_index();
+  ix->device = device; ix->nchr = n_chromosomes; ix->n_iv = n_iv; ix->E = E;
+  for (int e = 0; e < E; ++e) {
+    if (el->elem_strand[e] == MM_STRAND_F) ix->elemF |= 1ull << e;
+    if (el->elem_strand[e] == MM_STRAND_R) ix->elemR |= 1ull << e;
+    if (el->is_up[e]) ix->elemUp |= 1ull << e;
+    if (el->is_down[e]) ix->elemDown |= 1ull << e;
+  }
+  for (int e = 0; e < 64; ++e) {
+    ix->lineMask[e] = 0;
+    if (e < E) for (int f = 0; f < E; ++f) if (el->line_of[f] == el->line_of[e]) ix->lineMask[e] |= 1ull << f;
+  }
+  // validate + per-chromosome ranges
+  std::vector<u32> cs(n_chromosomes, 0), ce(n_chromosomes, 0);
+  std::vector<int64_t> maxEnd(n_chromosomes, -1);
+  std::vector<bool> seen(n_chromosomes, false);
+  for (size_t i = 0; i < n_iv; ++i) {
+    const int c = chr[i];
+    if (c < 0 || c >= n_chromosomes) { delete ix; return fail(MM_ERR_ARG, "mm_index_create: chromosome id out of range"); }
+    if (type[i] >= E) { delete ix; return fail(MM_ERR_ARG, "mm_index_create: element id out of range"); }
+    if (start[i] < 0 || end[i] < 0 || start[i] > 0x7FFFFFF0 || end[i] > 0x7FFFFFF0) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: coordinate outside [0, 2^31)"); }
+    if (i > 0 && (chr[i - 1] > c || (chr[i - 1] == c && start[i - 1] > start[i]))) { delete ix; return fail(MM_ERR_ARG, "mm_index_create: intervals must be sorted by (chromosome, start)"); }
+    if (!seen[c]) { seen[c] = true; cs[c] = (u32) i; }
+    ce[c] = (u32) i + 1;
+    if (end[i] > maxEnd[c]) maxEnd[c] = end[i];
+  }
+  // bin width
+  int shift = bin_shift;
+  auto total_bins = [&](int sh) { u64 t = 0; for (int c = 0; c < n_chromosomes; ++c) if (seen[c]) t += (u64) (maxEnd[c] >> sh) + 2; return t; };
+  if (shift <= 0) { shift = 10; while (total_bins(shift) > (6ull << 20)) ++shift; }
+  if (shift > 30) { delete ix; return fail(MM_ERR_ARG, "mm_index_create: bin_shift too large"); }
+  ix->shift = shift;
+  std::vector<u32> binBase(n_chromosomes, 0), nBins(n_chromosomes, 0), ivEnd(n_chromosomes, 0);
+  u64 nbt = 0;
+  for (int c = 0; c < n_chromosomes; ++c) {
+    if (!seen[c]) continue;
+    nBins[c] = (u32) (maxEnd[c] >> shift) + 1; binBase[c] = (u32) nbt; ivEnd[c] = ce[c];
+    nbt += nBins[c] + 1;
+  }
+  ix->n_bins = nbt;
+  std::vector<uint2> bins(nbt);
+  // active-list sizes: interval i is open at boundary b*W for b in [(start>>sh)+1, min((end+1)>>sh, nb-1)]
+  std::vector<u32> actCnt(nbt, 0);
+  for (size_t i = 0; i < n_iv; ++i) {
+    const int c = chr[i];
+    const u32 b0 = ((u32) start[i] >> shift) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> shift, nBins[c] - 1);
+    for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) ++actCnt[binBase[c] + b];
+  }
+  u64 na = 0;
+  for (u64 k = 0; k < nbt; ++k) { bins[k].y = (u32) na; na += actCnt[k]; }
+  if (na >= 0xFFFFFFF0ull) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: active lists too large; raise bin_shift"); }
+  ix->n_act = na;
+  // records
+  std::vector<int4> iv(n_iv), act(na ? na : 1);
+  for (int c = 0; c < n_chromosomes; ++c) {
+    if (!seen[c]) continue;
+    int pm = -1;
+    for (u32 i = cs[c]; i < ce[c]; ++i) {
+      iv[i] = make_int4(start[i], end[i], (int) type[i] | ((strand[i] == MM_STRAND_F) ? 0x100 : 0), pm);
+      if (end[i] > pm) pm = end[i];
+    }
+    // first[b] = first interval with start >= b*W
+    u32 p = cs[c];
+    for (u32 b = 0; b <= nBins[c]; ++b) {
+      const int64_t x = (int64_t) b << shift;
+      while (p < ce[c] && start[p] < x) ++p;
+      bins[binBase[c] + b].x = p;
+    }
+  }
+  {
+    std::vector<u32> cur(nbt);
+    for (u64 k = 0; k < nbt; ++k) cur[k] = bins[k].y;
+    for (size_t i = 0; i < n_iv; ++i) {
+      const int c = chr[i];
+      const u32 b0 = ((u32) start[i] >> shift) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> shift, nBins[c] - 1);
+      for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) act[cur[binBase[c] + b]++] = iv[i];
+    }
+  }
+  auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(d, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  hipError_t e;
+  if ((e = up((void **) &ix->d_iv, iv.data(), n_iv * sizeof(int4))) != hipSuccess ||
+      (e = up((void **) &ix->d_act, act.data(), na * sizeof(int4))) != hipSuccess ||
+      (e = up((void **) &ix->d_bins, bins.data(), nbt * sizeof(uint2))) != hipSuccess ||
+      (e = up((void **) &ix->d_chrBinBase, binBase.data(), n_chromosomes * 4)) != hipSuccess ||
+      (e = up((void **) &ix->d_chrNBins, nBins.data(), n_chromosomes * 4)) != hipSuccess ||
+      (e = up((void **) &ix->d_chrIvEnd, ivEnd.data(), n_chromosomes * 4)) != hipSuccess) {
+    mm_index_destroy(ix);
+    return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
+  }
+  *out = ix;
+  return MM_OK;
+}
+
+extern "C" void mm_index_destroy(mm_index *ix) {
+  if (!ix) return;
+  (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_bins);
+  (void) hipFree(ix->d_chrBinBase); (void) hipFree(ix->d_chrNBins); (void) hipFree(ix->d_chrIvEnd);
+  delete ix;
+}
+
+extern "C" int mm_index_info(const mm_index *ix, uint64_t info[4]) {
+  if (!ix || !info) return fail(MM_ERR_ARG, "mm_index_info: null argument");
+  info[0] = ix->n_iv * sizeof(int4); info[1] = ix->n_bins * sizeof(uint2); info[2] = ix->n_act * sizeof(int4); info[3] = (u64) ix->shift;
+  return MM_OK;
+}
+
+static void ctx_free_batch(mm_ctx *c) {
+  (void) hipFree(c->d_aln); (void) hipFree(c->d_nh); (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey);
+  (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
+  (void) hipFree(c->d_hist); (void) hipFree(c->d_tile);
+  c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr;
+  c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr; c->d_tile = nullptr;
+  c->cap = 0;
+}
+
+extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options *opt, void *stream) {
+  if (!out || !ix || !opt) return fail(MM_ERR_ARG, "mm_ctx_create: null argument");
+  *out = nullptr;
+  if (opt->strategy == MM_STRAT_RANDOM)
+    return fail(MM_ERR_ARG, "mm_ctx_create: -y random replays libc rand() in file order and is not a device strategy");
+  if (opt->strategy < 0 || opt->strategy > MM_STRAT_RATIO || opt->overlap_mode < 0 || opt->overlap_mode > MM_OVL_NT ||
+      opt->strandedness < 0 || opt->strandedness > MM_STRANDED_R)
+    return fail(MM_ERR_ARG, "mm_ctx_create: bad option value");
+  int rc = device_check(ix->device);
+  if (rc) return rc;
+  mm_ctx *c = new mm_ctx();
+  c->ix = ix; c->opt = *opt;
+  if (stream) c->stream = (hipStream_t) stream;
+  else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+  HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
+  HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
+  HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
+  HIPCHK(hipMalloc((void **) &c->d_rowTot, 256 * 4)); HIPCHK(hipMalloc((void **) &c->d_M, 4));
+  *out = c;
+  return mm_reset(c);
+}
+
+extern "C" void mm_ctx_destroy(mm_ctx *c) {
+  if (!c) return;
+  (void) hipStreamSynchronize(c->stream);
+  for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
+  ctx_free_batch(c);
+  (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
+  (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M);
+  (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
+  if (c->own_stream) (void) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int mm_reset(mm_ctx *c) {
+  if (!c) return fail(MM_ERR_ARG, "mm_reset: null context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipMemsetAsync(c->G.key, 0, GT_CAP * 8, c->stream)); HIPCHK(hipMemsetAsync(c->G.cnt, 0, GT_CAP * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->G.sum, 0, GT_CAP * 8, c->stream)); HIPCHK(hipMemsetAsync(c->G.err, 0, 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(u64), c->stream)); HIPCHK(hipMemsetAsync(c->d_walk, 0, 2 * sizeof(u64), c->stream));
+  if (c->qcap) {
+    HIPCHK(hipMemsetAsync(c->d_grpRem, 0, c->qcap * 4, c->stream)); HIPCHK(hipMemsetAsync(c->d_grpU, 0, c->qcap * 8, c->stream));
+  }
+  c->finalized = false;
+  c->last_n = 0;
+  return MM_OK;
+}
+
+static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
+  if (n <= c->cap && (!need_copy || c->d_aln)) return MM_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  size_t cap = std::max<size_t>(n, 1 << 16);
+  if (n > c->cap) {
+    ctx_free_batch(c);
+    const size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
+    HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4));
+    HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
+    HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
+    HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4)); HIPCHK(hipMalloc((void **) &c->d_tile, (nblk + 1) * 4));
+    c->cap = cap;
+  }
+  if (need_copy && !c->d_aln) {
+    HIPCHK(hipMalloc((void **) &c->d_aln, c->cap * sizeof(int4))); HIPCHK(hipMalloc((void **) &c->d_nh, c->cap * 4));
+  }
+  return MM_OK;
+}
+
+static int ensure_qids(mm_ctx *c, u64 qid_bound) {
+  if (qid_bound <= c->qcap) return MM_OK;
+  if (qid_bound > 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "qid_bound exceeds 2^32");
+  u64 ncap = std::max<u64>(qid_bound + qid_bound / 2, 1 << 16);
+  ncap = std::min<u64>(ncap, 0xFFFFFFF0ull);
+  u32 *nr = nullptr; u64 *nu = nullptr;
+  HIPCHK(hipMalloc((void **) &nr, ncap * 4)); HIPCHK(hipMalloc((void **) &nu, ncap * 8));
+  HIPCHK(hipMemsetAsync(nr, 0, ncap * 4, c->stream)); HIPCHK(hipMemsetAsync(nu, 0, ncap * 8, c->stream));
+  if (c->qcap) {
+    HIPCHK(hipMemcpyAsync(nr, c->d_grpRem, c->qcap * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(nu, c->d_grpU, c->qcap * 8, hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
+  c->d_grpRem = nr; c->d_grpU = nu; c->qcap = ncap;
+  return MM_OK;
+}
+
+static void fill_params(const mm_ctx *c, ProbeParams &P) {
+  const mm_index *ix = c->ix;
+  P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
+  P.chrBinBase = ix->d_chrBinBase; P.chrNBins = ix->d_chrNBins; P.chrIvEnd = ix->d_chrIvEnd;
+  P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
+  P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
+  P.overlapMode = c->opt.overlap_mode; P.overlapValue = c->opt.overlap_value;
+  P.strandedness = c->opt.strandedness; P.strategy = c->opt.strategy; P.keep = c->opt.keep_hit_masks;
+  memcpy(P.lineMask, ix->lineMask, sizeof(P.lineMask));
+}
+
+static int bits_for(u64 bound) {
+  int b = 1;
+  while (b < 32 && (1ull << b) < bound) ++b;
+  return b;
+}
+
+// stable sort of the M (device-side count) pairs in (kA,vA) by the low `bits` bits; result pointers returned
+static int sort_pairs(mm_ctx *c, size_t n_cap, int bits, u32 **sk, u32 **sv) {
+  const u32 nblk = (u32) ((n_cap + RS_TILE - 1) / RS_TILE);
+  u32 *kin = c->d_kA, *vin = c->d_vA, *kout = c->d_kB, *vout = c->d_vB;
+  for (int shift = 0; shift < bits; shift += 8) {
+    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, c->d_M, shift, c->d_hist, nblk);
+    hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot);
+    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, shift, c->d_hist,
+                       c->d_rowTot, nblk);
+    std::swap(kin, kout); std::swap(vin, vout);
+  }
+  *sk = kin; *sv = vin;
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *nh, size_t n, uint64_t qid_bound, int on_device) {
+  if (!c) return fail(MM_ERR_ARG, "mm_annotate_batch: null context");
+  if (c->finalized) return fail(MM_ERR_STATE, "mm_annotate_batch: context already finalized (call mm_reset)");
+  if (n == 0) return MM_OK;
+  if (!aln) return fail(MM_ERR_ARG, "mm_annotate_batch: null tuples");
+  if (n > 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_annotate_batch: batch larger than 2^32 tuples");
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = ensure_batch(c, n, !on_device);
+  if (rc) return rc;
+  const bool dflt = c->opt.strategy == MM_STRAT_DEFAULT, ratio = c->opt.strategy == MM_STRAT_RATIO;
+  if (dflt && nh) { rc = ensure_qids(c, qid_bound ? qid_bound : 1); if (rc) return rc; }
+  const int4 *d_aln = (const int4 *) aln;
+  const u32 *d_nh = nh;
+  if (!on_device) {
+    PhaseTimer t(c, MM_PHASE_H2D);
+    HIPCHK(hipMemcpyAsync(c->d_aln, aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->stream));
+    if (nh) HIPCHK(hipMemcpyAsync(c->d_nh, nh, n * 4, hipMemcpyHostToDevice, c->stream));
+    d_aln = c->d_aln; d_nh = nh ? c->d_nh : nullptr;
+  }
+  ProbeParams P;
+  fill_params(c, P);
+  const bool need_groups = (dflt && d_nh) || ratio;
+  const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
+  u64 *hm = c->d_hm;
+  u32 *gkey = need_groups ? c->d_gkey : nullptr;
+  {
+  PhaseTimer t(c, MM_PHASE_PROBE);
+  switch (c->opt.overlap_mode) {
+    case MM_OVL_INCLUSION:
+      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+      break;
+    case MM_OVL_PC:
+      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+      break;
+    default:
+      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+  }
+  }
+  HIPCHK(hipGetLastError());
+  c->last_n = n;
+  if (need_groups) {
+    const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
+    {
+      PhaseTimer t(c, MM_PHASE_COMPACT);
+      hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, n, c->d_tile);
+      hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, c->stream, c->d_tile, nblk, c->d_M);
+      hipLaunchKernelGGL(k_emit_pairs, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, n, c->d_tile, c->d_kA, c->d_vA);
+    }
+    u32 *sk, *sv;
+    {
+      PhaseTimer t(c, MM_PHASE_SORT);
+      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, &sk, &sv);
+    }
+    if (rc) return rc;
+    PhaseTimer t(c, MM_PHASE_MERGE);
+    if (dflt)
+      hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, sk, sv, c->d_M, d_nh, hm, c->d_grpRem, c->d_grpU, c->G, c->d_stats);
+    else
+      hipLaunchKernelGGL(k_ratio_accum, dim3(grid), dim3(256), 0, c->stream, sk, sv, c->d_M, d_nh, c->G);
+    HIPCHK(hipGetLastError());
+  }
+  return MM_OK;
+}
+
+static int check_table(mm_ctx *c) {
+  u32 err = 0;
+  HIPCHK(hipMemcpyAsync(&err, c->G.err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (err) return fail(MM_ERR_TABLE_FULL, "more than 65536 distinct element sets");
+  return MM_OK;
+}
+
+extern "C" int mm_sync(mm_ctx *c) {
+  if (!c) return fail(MM_ERR_ARG, "mm_sync: null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return check_table(c);
+}
+
+extern "C" int mm_finalize(mm_ctx *c) {
+  if (!c) return fail(MM_ERR_ARG, "mm_finalize: null context");
+  if (!c->finalized && c->opt.strategy == MM_STRAT_DEFAULT && c->qcap) {
+    PhaseTimer t(c, MM_PHASE_FLUSH);
+    hipLaunchKernelGGL(k_flush_pending, dim3(256 * 4), dim3(256), 0, c->stream, c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
+    HIPCHK(hipGetLastError());
+  }
+  c->finalized = true;
+  return mm_sync(c);
+}
+
+extern "C" int mm_set_profiling(mm_ctx *c, int on) {
+  if (!c) return fail(MM_ERR_ARG, "mm_set_profiling: null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
+  c->spans.clear();
+  c->profiling = on != 0;
+  return MM_OK;
+}
+
+extern "C" int mm_get_phase_ms(mm_ctx *c, double ms[MM_N_PHASES], uint64_t launches[MM_N_PHASES]) {
+  if (!c || !ms || !launches) return fail(MM_ERR_ARG, "mm_get_phase_ms: null argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int p = 0; p < MM_N_PHASES; ++p) { ms[p] = 0; launches[p] = 0; }
+  for (auto &s : c->spans) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, s.a, s.b));
+    ms[s.phase] += (double) t; ++launches[s.phase];
+  }
+  return MM_OK;
+}
+
+extern "C" int mm_get_stats(mm_ctx *c, uint64_t stats[MM_N_STATS]) {
+  if (!c || !stats) return fail(MM_ERR_ARG, "mm_get_stats: null argument");
+  u64 h[8];
+  HIPCHK(hipMemcpyAsync(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < MM_N_STATS; ++i) stats[i] = h[i];
+  return MM_OK;
+}
+
+extern "C" int mm_get_rows(mm_ctx *c, uint64_t *masks, double *sums, size_t cap, size_t *n_rows) {
+  if (!c || !n_rows) return fail(MM_ERR_ARG, "mm_get_rows: null argument");
+  std::vector<u64> k(GT_CAP), v(GT_CAP);
+  std::vector<double> s(GT_CAP);
+  HIPCHK(hipMemcpyAsync(k.data(), c->G.key, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(v.data(), c->G.cnt, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(s.data(), c->G.sum, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const bool ratio = c->opt.strategy == MM_STRAT_RATIO;
+  size_t nr = 0;
+  for (u32 i = 0; i < GT_CAP; ++i) {
+    if (!k[i]) continue;
+    if (!ratio && v[i] == 0) continue;  // slot created but never counted cannot happen outside ratio; be safe
+    if (masks && nr < cap) { masks[nr] = k[i]; if (sums) sums[nr] = ratio ? s[i] : (double) v[i]; }
+    ++nr;
+  }
+  *n_rows = nr;
+  if (masks && nr > cap) return fail(MM_ERR_ARG, "mm_get_rows: capacity too small");
+  return MM_OK;
+}
+
+extern "C" int mm_get_hit_masks(mm_ctx *c, uint64_t *out, size_t n) {
+  if (!c || !out) return fail(MM_ERR_ARG, "mm_get_hit_masks: null argument");
+  if (!c->opt.keep_hit_masks) return fail(MM_ERR_STATE, "mm_get_hit_masks: context created without keep_hit_masks");
+  if (n > c->last_n) return fail(MM_ERR_ARG, "mm_get_hit_masks: n exceeds the last batch");
+  HIPCHK(hipMemcpyAsync(out, c->d_hm, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
+  if (!c || !out) return fail(MM_ERR_ARG, "mm_get_walk_stats: null argument");
+  HIPCHK(hipMemcpyAsync(out, c->d_walk, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+extern "C" int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_params *p, void *stream) {
+  if (!d_aln || !p || !p->chr_len) return fail(MM_ERR_ARG, "mm_synth_fill: null argument");
+  if (p->n_chromosomes < 1 || p->n_chromosomes > 64) return fail(MM_ERR_ARG, "mm_synth_fill: 1..64 chromosomes");
+  if (p->nh_max < 1 || p->nh_max > 4096 || p->read_len < 1) return fail(MM_ERR_ARG, "mm_synth_fill: bad nh_max/read_len");
+  SynthDev S;
+  S.seed = p->seed; S.first = p->first; S.read_len = p->read_len; S.nh_max = p->nh_max; S.nchr = p->n_chromosomes;
+  S.scatter_log2 = p->scatter_log2;
+  S.cum[0] = 0;
+  for (int c = 0; c < p->n_chromosomes; ++c) {
+    if (p->chr_len[c] < 1 || p->chr_len[c] > 0x7FFFFF00) return fail(MM_ERR_RANGE, "mm_synth_fill: chromosome length");
+    S.cum[c + 1] = S.cum[c] + (u64) p->chr_len[c];
+  }
+  if (n == 0) return MM_OK;
+  const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, (hipStream_t) stream, S, (int4 *) d_aln, (u32 *) d_nh, n);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}

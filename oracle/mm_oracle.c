@@ -221,6 +221,12 @@ static size_t rc_slot(rc_map *m, uint64_t k) {
   return s;
 }
 
+/* the slot must be resolved before m->val is read: rc_slot may grow (reallocate) the table */
+static void rc_add(rc_map *m, uint64_t k, double x) {
+  size_t s = rc_slot(m, k);
+  m->val[s] += x;
+}
+
 /* readCounts / rawCounts: unordered_map<string, pair<unsigned, vector<size_t>>> mmannot.cpp:1656-1657,
  * keyed here by the dense name id.  'present' distinguishes "in the map". */
 typedef struct { uint32_t remaining; uint32_t raw; uint64_t set; uint8_t present; } grp_state;
@@ -295,7 +301,7 @@ int mmo_run(const mmo_config *c, const mmo_index *ix, const mmo_reads *rd, mmo_r
         g->remaining--; g->set |= regions;
         if (g->remaining == 0) {
           if (g->set) {                                                   /* :1685 */
-            rc.val[rc_slot(&rc, g->set)] += 1.0;                          /* ++regionCounts[...] :1688 */
+            rc_add(&rc, g->set, 1.0);                                     /* ++regionCounts[...] :1688 */
             if (__builtin_popcountll(g->set) == 1) nRescued++;            /* :1689 */
           }
           g->present = 0; g->set = 0;                                     /* erase :1698-1699 */
@@ -314,7 +320,7 @@ int mmo_run(const mmo_config *c, const mmo_index *ix, const mmo_reads *rd, mmo_r
           }
         }
         if (c->strategy != MMO_STRAT_RANDOM || output) {                  /* :1727-1730 */
-          rc.val[rc_slot(&rc, regions)] += (c->strategy == MMO_STRAT_RATIO) ? 1.0 / (double) nh : 1.0;
+          rc_add(&rc, regions, (c->strategy == MMO_STRAT_RATIO) ? 1.0 / (double) nh : 1.0);
         }
       }
       ++nReads;                                                           /* :1737 */
@@ -326,7 +332,7 @@ int mmo_run(const mmo_config *c, const mmo_index *ix, const mmo_reads *rd, mmo_r
     for (int64_t q = 0; q <= max_qid; ++q) {
       grp_state *g = &grp[q];
       if (g->present && g->set) {
-        rc.val[rc_slot(&rc, g->set)] += 1.0;
+        rc_add(&rc, g->set, 1.0);
         if (g->raw > 1 && __builtin_popcountll(g->set) == 1) nRescued++;  /* :1789 */
       }
     }

@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mmannot_amd.h declares.
+No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mmannot_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    from mmannot_amd import _lib
+    l = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(l, s), f"{s} declared in include/mmannot_amd.h but not exported"
+        assert s in _lib.SYMBOLS, f"{s} has no ctypes signature in mmannot_amd/_lib.py"
+
+
+def test_host_finalisation_helpers(oracle):
+    """mm_round_to_uint / mm_sort_rows are host code: compare with the oracle's restatement."""
+    from mmannot_amd import _lib
+    l = _lib.lib()
+    for v in (0.0, 0.49999999999999994, 0.5, 1.5, 2.5, 1e9 + 0.5, 4294967295.6, 4294967296.0, float("inf"), float("nan")):
+        assert l.mm_round_to_uint(v) == oracle.lib().mmo_round_to_uint(v)
+    rng = np.random.default_rng(5)
+    masks = np.unique(rng.integers(1, 1 << 22, 500, dtype=np.uint64) & rng.integers(1, 1 << 22, 500, dtype=np.uint64))
+    masks = masks[masks != 0]
+    want = sorted(masks.tolist(), key=lambda m: [i for i in range(64) if (m >> i) & 1])
+    got = masks.copy()
+    sums = got.astype(np.float64)
+    l.mm_sort_rows(got.ctypes.data, sums.ctypes.data, len(got))
+    assert got.tolist() == want and (sums == got.astype(np.float64)).all()
+    for a, b in zip(want[:-1], want[1:]):
+        assert oracle.lib().mmo_cmp_lists(a, b) < 0
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the compute entry points must fail with MM_ERR_HIP, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    import mmannot_amd as m
+    cfg = m.Config([m.ConfigElement("a", "b", 0, 0)])
+    try:
+        m.IntervalIndex(cfg, [0], [1], [10], [0], [1], 1)
+    except m.MMError as e:
+        assert e.code == 2
+    else:
+        raise AssertionError("index creation succeeded without a GPU")

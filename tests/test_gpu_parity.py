@@ -1,0 +1,140 @@
+"""GPU: the HIP path (through the C ABI) against (a) the golden vectors of the compiled reference
+and (b) the CPU oracle on seeded synthetic inputs — bit-exact: tables, the seven counters, and the
+per-hit element sets."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import synth_ref as sr
+
+pytestmark = pytest.mark.gpu
+
+ALL1 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def to_cfg(mm, desc):
+    return mm.Config.from_json(desc.to_json())
+
+
+def run_gpu(mm, cfg, ix, reads, *, overlap, strandedness, strategy, batches=1, keep=True, bin_shift=0):
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], ix["n_chromosomes"], bin_shift=bin_shift)
+    ctr = mm.Counter(index, overlap=overlap, strandedness=strandedness, strategy=strategy, keep_hit_masks=keep)
+    n = len(reads["start"])
+    aln = mm.pack_alignments(reads["tid"], reads["start"], reads["end"], reads["strand"], reads["qid"])
+    nh = reads["nh"].astype(np.uint32)
+    qb = int(reads["qid"].max()) + 1 if n else 1
+    hm = []
+    cuts = np.linspace(0, n, batches + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            ctr.add_batch(aln[a:b], nh[a:b], qb)
+            ctr.sync()
+            if keep:
+                hm.append(ctr.hit_masks(b - a))
+    ctr.flush()
+    masks, sums = ctr.getCounts()
+    stats = ctr.stats()
+    table = mm.TableCount(cfg, 1)
+    table.add_rows(masks, sums)
+    res = dict(table=table.dump(["test_dataset"]), stats=stats, hit=np.concatenate(hm) if hm else None, masks=masks, sums=sums,
+               stderr=ctr.dump("$REF/test_dataset.bam"))
+    ctr.close(); index.close()
+    return res
+
+
+D, CASES, READS, HITMASKS = gu.load_test_dataset()
+NAMES = [k for k in CASES if not k.startswith("fail") and "random" not in k]
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("batches", [1, 7])
+def test_reference_golden(gpu_lib, name, batches):
+    mm = gpu_lib
+    c = CASES[name]
+    o = gu.parse_args(c["args"])
+    cfg = mm.Config.from_json(json.load(open(os.path.join(D, f"config_{c['config']}.json"))))
+    ix = gu.load_index(os.path.join(D, f"index_{c['index']}.tsv.gz"))
+    r = run_gpu(mm, cfg, ix, READS, overlap=o["overlap"], strandedness=o["strandedness"], strategy=o["strategy"], batches=batches)
+    assert r["table"] == c["table"]
+    for k, v in gu.parse_stderr_stats(c["stderr"]).items():
+        assert r["stats"][k] == v, k
+    assert r["stderr"] in c["stderr"]
+    m = r["hit"][r["hit"] != ALL1]
+    assert len(m) == len(HITMASKS[name]) and (m == HITMASKS[name]).all()
+
+
+SYNTH = [(seed, l, s, y) for seed in (1, 2, 3) for l in (-1.0, 0.0, 0.4, 0.83, 1.0, 25.0) for s in ("U", "F", "R")
+         for y in ("default", "unique", "ratio")]
+
+
+@pytest.mark.parametrize("seed,l,s,y", SYNTH)
+def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
+    mm = gpu_lib
+    rng = np.random.default_rng(1000 * seed + int(abs(l) * 10))
+    desc = sr.random_config(rng, n_lines=int(rng.integers(3, 12)), max_per_line=int(rng.integers(1, 5)))
+    ix = sr.random_index(rng, desc.E, nchr=4, n=3000, maxpos=150000, skip_chr=3 if seed == 2 else None)
+    reads = sr.random_reads(rng, ix, n=20000, nchr=4, maxpos=150000, nh_max=7)
+    ref = oracle.run(desc, ix, reads, overlap=l, strandedness=s, strategy=y, want_hit_mask=True)
+    cfg = to_cfg(mm, desc)
+    for batches, shift in ((1, 0), (5, 8), (3, 14)):
+        r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s, strategy=y, batches=batches, bin_shift=shift)
+        assert (r["hit"] == ref.hit_mask).all(), f"hit masks differ (batches={batches}, shift={shift})"
+        assert r["stats"] == ref.stats
+        assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+        if y == "ratio":  # the double accumulators themselves must be bit-identical (file-order adds)
+            got = dict(zip(r["masks"].tolist(), r["sums"].view(np.uint64).tolist()))
+            want = dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
+            assert got == want
+
+
+def test_empty_and_edge_batches(gpu_lib, oracle):
+    mm = gpu_lib
+    rng = np.random.default_rng(77)
+    desc = sr.random_config(rng, 4, 2)
+    ix = sr.random_index(rng, desc.E, nchr=2, n=50, maxpos=5000)
+    cfg = to_cfg(mm, desc)
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], 2)
+    ctr = mm.Counter(index, strandedness="U")
+    ctr.add_batch(np.zeros(0, dtype=mm.ALN_DTYPE), np.zeros(0, dtype=np.uint32), 1)   # empty batch
+    ctr.flush()
+    assert ctr.stats()["nHits"] == 0 and len(ctr.getCounts()[0]) == 0
+    assert "No hit." in ctr.dump("x.bam")
+    with pytest.raises(mm.MMError):            # Counter::read after the flush needs clear()
+        ctr.add_batch(np.zeros(1, dtype=mm.ALN_DTYPE), None, 1)
+    ctr.clear()
+    # a single read, NH absent (NULL nh array = all 1)
+    s = int(ix["start"][0]); e = int(ix["start"][0])
+    ctr.add_batch(mm.pack_alignments([int(ix["chr"][0])], [s], [e], [1], [0]), None, 1)
+    ctr.flush()
+    ref = oracle.run(desc, ix, dict(tid=np.array([ix["chr"][0]], dtype=np.int32), start=np.array([s]), end=np.array([e]),
+                                    strand=np.array([1], dtype=np.uint8), nh=None, qid=np.array([0])), strandedness="U")
+    assert ctr.stats() == ref.stats
+    with pytest.raises(mm.MMError):            # -y random is not a device strategy
+        mm.Counter(index, strategy="random")
+    ctr.close(); index.close()
+
+
+def test_synth_generator_twin(gpu_lib):
+    """mm_synth_fill (device) == tests/synth_ref.synth_tuples (numpy), so full-size device-generated
+    workloads can be checked against the oracle on a prefix."""
+    import ctypes as C
+    import torch
+    mm = gpu_lib
+    from mmannot_amd import _lib
+    chr_len = np.array([30_000_000, 19_000_000, 23_000_000, 18_000_000, 27_000_000], dtype=np.int64)
+    for nh_max, sc, first in ((1, 0, 0), (20, 0, 12345), (20, 10, 1 << 20), (5, 16, 777)):
+        n = 100_000
+        aln = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        nh = torch.zeros(n, dtype=torch.int32, device="cuda")
+        p = _lib.SynthParams(42, first, 100, nh_max, len(chr_len), chr_len.ctypes.data, sc)
+        _lib.check(_lib.lib().mm_synth_fill(aln.data_ptr(), nh.data_ptr(), n, C.byref(p), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        a = aln.cpu().numpy().view(np.uint32)
+        t = sr.synth_tuples(42, first, n, 100, nh_max, chr_len, sc)
+        assert (a[:, 0].astype(np.int64) == t["start"]).all() and (a[:, 1].astype(np.int64) == t["end"]).all()
+        assert ((a[:, 2] >> 1).astype(np.int64) - 1 == t["tid"]).all() and ((a[:, 2] & 1) == t["strand"]).all()
+        assert (a[:, 3].astype(np.int64) == t["qid"]).all()
+        assert (nh.cpu().numpy().view(np.uint32) == t["nh"]).all()
