@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — annotated alignments / second of the overlap-and-count hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2] [--batch-log2 B]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run; backend "nccl" = RCCL).
+A step = one batch of 2^B synthetic alignment tuples, generated on the device beforehand (inputs are
+resident in HBM when the timed region starts), pushed through mm_annotate_batch: probe -> strand / -l
+filter -> priority selection -> multi-hit merge -> per-set counts.  The timed region is K steps plus the
+end-of-file flush and the cross-rank table merge.  Prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json configs):
+  c3 (default): 100 bp single-end reads, read groups with NH = 1..20 (exactly NH hits each, scattered over
+      windows of 2^16 tuples), HS38-scale synthetic annotation (~1.27 M intervals, 22 Order elements),
+      -y default -s F -l -1.  This is the configuration the north-star target is quoted on.
+  c2: 50 bp reads, NH = 1, TAIR10-scale annotation (~0.55 M intervals, 14 elements).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG_PROBE = 32.0  # algorithmic bytes / alignment of the probe kernel: 16 B tuple + 16 B index
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--batch-log2", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=24)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mmannot_amd as mm
+    from mmannot_amd import _lib, synth
+    from mmannot_amd.dist import merge_counts
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    # ---------------- annotation (same on every rank) -> device index
+    if args.workload == "c3":
+        an = synth.synth_annotation("hs38", seed=args.seed, scale=1.5)
+        read_len, nh_max, scatter = 100, 20, 16
+        wname = "c3: synthetic 100bp SE reads, NH=1..20 groups, HS38-scale annotation, -y default -s F -l -1"
+    else:
+        an = synth.synth_annotation("tair10", seed=args.seed, scale=1.0)
+        read_len, nh_max, scatter = 50, 1, 0
+        wname = "c2: synthetic 50bp SE reads, NH=1, TAIR10-scale annotation, -y default -s F -l -1"
+    cfg = mm.Config.from_json(an.config)
+    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank)
+    info = index.info()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy="default", stream=stream)
+
+    # ---------------- inputs: W+K batches per rank, resident in HBM (rank-local stream, rank-local read-name ids)
+    B = 1 << args.batch_log2
+    nb = args.warmup + args.steps
+    chr_len = np.ascontiguousarray(an.chr_len, dtype=np.int64)
+    alns, nhs = [], []
+    for s in range(nb):
+        a = torch.empty((B, 4), dtype=torch.int32, device=dev)
+        h = torch.empty(B, dtype=torch.int32, device=dev) if nh_max > 1 else None
+        p = _lib.SynthParams(args.seed * 1000003 + rank, s * B, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter)
+        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), h.data_ptr() if h is not None else None, B, C.byref(p), stream))
+        alns.append(a); nhs.append(h)
+    torch.cuda.synchronize()
+    groups_per_tuple = (nh_max / (nh_max * (nh_max + 1) / 2.0)) if nh_max > 1 else 1.0
+
+    def qid_bound(step):  # exclusive bound of the read-name ids of batches 0..step
+        return int((step + 1) * B * groups_per_tuple) + nh_max + 2
+
+    def run_step(s):
+        ctr.add_batch_device(alns[s].data_ptr(), nhs[s].data_ptr() if nhs[s] is not None else None, B, qid_bound(s))
+
+    for s in range(args.warmup):
+        run_step(s)
+    ctr.sync()
+    ctr.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, nb):
+        run_step(s)
+    ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
+    masks, sums = ctr.getCounts()
+    stats = ctr.stats()
+    masks, sums, stats = merge_counts(masks, sums, stats, device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    phases = ctr.phase_ms()
+
+    # size-independent sanity of the whole job (every tuple was handed to scan(); every group counted at most once)
+    total_tuples = world * nb * B
+    assert stats["nHits"] == total_tuples, (stats, total_tuples)
+    assert int(np.rint(sums).sum()) <= stats["nReads"]
+
+    if rank == 0:
+        value = world * args.steps * B / elapsed
+        dom = max(("probe", "sort", "merge", "compact"), key=lambda p: phases[p][0])
+        probe_ms, probe_n = phases["probe"]
+        avg_probe_s = probe_ms / max(1, probe_n) / 1e3
+        achieved = B_ALG_PROBE * B / avg_probe_s / 1e9
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get(args.workload, {}).get("k_probe_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "annotated alignments/sec", "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32/u64 (f64 only under -y ratio)", "data": "synthetic",
+            "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "order_elements": len(an.config),
+                       "index_bytes": info, "sharding": "by read name, table merged by all_gather+all_reduce"},
+            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
+                         "dominant_phase": dom},
+            "phase_ms_per_step": {p: phases[p][0] / max(1, args.steps) for p in phases},
+            "stats": stats, "table_rows": int(len(masks)),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, an, read_len, nh_max, scatter, chr_len)
+        print(json.dumps(out))
+    ctr.close(); index.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, an, read_len, nh_max, scatter, chr_len):
+    """The CPU restatement of the path (oracle/mm_oracle.c, kind "port", one thread) on a prefix of rank 0's stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_ref as sr
+    from oracle import mm_oracle as mo
+    n = 1 << args.cpu_sample_log2
+    t = sr.synth_tuples(args.seed * 1000003, 0, n, read_len, nh_max, chr_len, scatter)
+    desc = mo.ConfigDesc.from_json(an.config)
+    t0 = time.perf_counter()
+    r = mo.run(desc, an.as_index_dict(), t, overlap=-1.0, strandedness="F", strategy="default")
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"first 2^{args.cpu_sample_log2} alignments of rank 0's stream, oracle/mm_oracle.c single thread, {dt:.1f} s",
+            "stats": r.stats}
+
+
+if __name__ == "__main__":
+    main()
