@@ -151,6 +151,26 @@ uint32_t mm_round_to_uint(double v);
 /* std::sort over the vector<size_t> keys, mmannot.cpp:1883: sorts rows in place */
 void mm_sort_rows(uint64_t *masks, double *sums, size_t n_rows);
 
+/* ---- cold path (host, once per run): configuration file + GTF -> the sorted typed interval vector.
+ * Replaces Config::parse (mmannot.cpp:237-382) and the IntervalList constructor (mmannot.cpp:1094-1290),
+ * including Synonyms / Introns / Vicinity expansion and the reference's std::sort order. */
+typedef struct mm_annotation mm_annotation;
+int mm_annotation_load(mm_annotation **out, const char *config_path, const char *gtf_path, uint32_t upstream, uint32_t downstream);
+void mm_annotation_free(mm_annotation *a);
+const char *mm_annotation_error(void);                 /* message of the last failed mm_annotation_load (what the reference prints before exit(1)) */
+const char *mm_annotation_log(const mm_annotation *a); /* what the reference writes to stderr while loading */
+int32_t mm_annotation_n_elements(const mm_annotation *a);
+int32_t mm_annotation_n_chromosomes(const mm_annotation *a);
+size_t mm_annotation_n_intervals(const mm_annotation *a);
+const char *mm_annotation_element_name(const mm_annotation *a, int32_t e);  /* Config::getName, mmannot.cpp:445-462 */
+const char *mm_annotation_chromosome(const mm_annotation *a, int32_t c);
+int mm_annotation_chromosome_has_intervals(const mm_annotation *a, int32_t c); /* is the name a key of `bins` (mmannot.cpp:1278, 1293) */
+const char *mm_annotation_interval_id(const mm_annotation *a, size_t i);    /* TypedInterval::getId (for -M) */
+int mm_annotation_elements(const mm_annotation *a, mm_elements *out);       /* pointers stay owned by the annotation */
+int mm_annotation_intervals(const mm_annotation *a, const int32_t **chr, const int32_t **start, const int32_t **end,
+                            const uint8_t **type, const uint8_t **strand);
+int mm_index_from_annotation(mm_index **out, const mm_annotation *a, int device, int bin_shift);
+
 /* ---- synthetic workload generators for bench.py / tests (device kernels, counter-based RNG;
  * tests/synth_ref.py holds the numpy twin).  See DESIGN.md "Synthetic inputs". */
 typedef struct mm_synth_params {

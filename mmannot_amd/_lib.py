@@ -68,6 +68,20 @@ SYMBOLS = {
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mm_round_to_uint": (C.c_uint32, [C.c_double]),
     "mm_sort_rows": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mm_annotation_load": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32]),
+    "mm_annotation_free": (None, [C.c_void_p]),
+    "mm_annotation_error": (C.c_char_p, []),
+    "mm_annotation_log": (C.c_char_p, [C.c_void_p]),
+    "mm_annotation_n_elements": (C.c_int32, [C.c_void_p]),
+    "mm_annotation_n_chromosomes": (C.c_int32, [C.c_void_p]),
+    "mm_annotation_n_intervals": (C.c_size_t, [C.c_void_p]),
+    "mm_annotation_element_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "mm_annotation_chromosome": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "mm_annotation_chromosome_has_intervals": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mm_annotation_interval_id": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+    "mm_annotation_elements": (C.c_int, [C.c_void_p, C.POINTER(Elements)]),
+    "mm_annotation_intervals": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
+    "mm_index_from_annotation": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "mm_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(SynthParams), C.c_void_p]),
 }
 

@@ -286,3 +286,60 @@ def format_stats(stats: Dict[str, int], file_name: str) -> str:
     out.append(ps(stats["nAmbiguous"], "# ambiguous hits:              ", stats["nHits"]))
     out.append(ps(stats["nUnassigned"], "# unassigned hits:             ", stats["nHits"]))
     return "\n".join(out) + "\n"
+
+
+class Annotation:
+    """Config + IntervalList construction (mmannot.cpp:237-382, 1094-1290) done by the host library:
+    configuration file + GTF -> sorted typed intervals (cold path, once per run)."""
+
+    def __init__(self, config_path: str, gtf_path: str, upstream: int = 1000, downstream: int = 1000):
+        h = C.c_void_p()
+        rc = lib().mm_annotation_load(C.byref(h), config_path.encode(), gtf_path.encode(), upstream, downstream)
+        if rc != 0:
+            raise _lib.MMError(rc, lib().mm_annotation_error().decode(errors="replace"))
+        self._h = h
+        l = lib()
+        self.log = l.mm_annotation_log(h).decode(errors="replace")
+        E = l.mm_annotation_n_elements(h)
+        self.names = [l.mm_annotation_element_name(h, e).decode() for e in range(E)]
+        nc = l.mm_annotation_n_chromosomes(h)
+        self.chromosomes = [l.mm_annotation_chromosome(h, c).decode() for c in range(nc)]
+        self.chr_has_intervals = [bool(l.mm_annotation_chromosome_has_intervals(h, c)) for c in range(nc)]
+        n = l.mm_annotation_n_intervals(h)
+        self.n_intervals = n
+        ptrs = [C.c_void_p() for _ in range(5)]
+        check(l.mm_annotation_intervals(h, *[C.byref(p) for p in ptrs]))
+
+        def view(p, ct, cnt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(cnt,)).copy()
+        self.chr = view(ptrs[0], C.c_int32, n); self.start = view(ptrs[1], C.c_int32, n); self.end = view(ptrs[2], C.c_int32, n)
+        self.type = view(ptrs[3], C.c_uint8, n); self.strand = view(ptrs[4], C.c_uint8, n)
+        el = Elements()
+        check(l.mm_annotation_elements(h, C.byref(el)))
+        self.line_of = view(C.c_void_p(el.line_of), C.c_int32, E)
+        self.elem_strand = view(C.c_void_p(el.elem_strand), C.c_uint8, E)
+        self.is_up = view(C.c_void_p(el.is_up), C.c_uint8, E)
+        self.is_down = view(C.c_void_p(el.is_down), C.c_uint8, E)
+
+    def interval_id(self, i: int) -> str:
+        return lib().mm_annotation_interval_id(self._h, i).decode()
+
+    def config(self) -> "Config":
+        """The flattened Order as a Config (names are reproduced through source/type of the printed name)."""
+        els = []
+        for e, nm in enumerate(self.names):
+            base = nm[:-4] if nm.endswith((" (+)", " (-)")) else nm
+            src, _, typ = base.partition(":")
+            els.append(ConfigElement(src, typ, int(self.elem_strand[e]), int(self.line_of[e])))
+        return Config(els)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm_annotation_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -129,12 +129,47 @@ def gen_test_dataset():
     np.savez_compressed(os.path.join(out, "hitmasks.npz"), **hitmasks)
 
 
+def gen_builder():
+    """Interval dumps that pin the product's config+GTF builder (mm_annot.cpp) beyond the HS38 config:
+    the wildcard/synonym config shipped as config.txt on the chrY GTF, and seeded synthetic GTFs
+    (mmannot_amd.synth.gtf_text) under their own configs, also with -d/-D variants."""
+    from mmannot_amd import synth
+    out = os.path.join(GOLD, "builder")
+    os.makedirs(out, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="mmgoldb")
+    bam = os.path.join(REF, "test_dataset.bam")
+    meta = {}
+
+    def one(name, cfg_path, gtf_path, extra):
+        dump = os.path.join(tmp, name + ".dump")
+        rc, so, se = mo.run_ref("mmannot_dump", ["-a", gtf_path, "-r", bam, "-c", cfg_path, "-s", "U", "-o", os.path.join(tmp, "t.tsv")] + extra, dump=dump)
+        meta[name] = dict(rc=rc, stderr_head=se.split("Reading BAM")[0].replace(REF, "$REF").replace(tmp, "$TMP"), args=extra)
+        if rc == 0:
+            iv, _ = mo.parse_dump(dump)
+            write_iv_dump(iv, os.path.join(out, f"index_{name}.tsv.gz"))
+        print("builder", name, "rc", rc, file=sys.stderr)
+
+    one("chrY_config_txt", os.path.join(REF, "config.txt"), os.path.join(REF, "test_dataset.gtf"), [])
+    one("chrY_configTest", os.path.join(REF, "configTest.txt"), os.path.join(REF, "test_dataset.gtf"), [])
+    for shape, seed, scale in (("tair10", 5, 0.02), ("hs38", 6, 0.01)):
+        an = synth.synth_annotation(shape, seed=seed, scale=scale, keep_genes=True)
+        gtf = os.path.join(tmp, f"{shape}.gtf"); open(gtf, "w").write(synth.gtf_text(an))
+        cfgp = os.path.join(tmp, f"{shape}.cfg"); open(cfgp, "w").write(synth.config_text(shape))
+        one(f"synth_{shape}_s{seed}", cfgp, gtf, [])
+        one(f"synth_{shape}_s{seed}_d300_D50", cfgp, gtf, ["-d", "300", "-D", "50"])
+        meta[f"synth_{shape}_s{seed}"]["synth"] = dict(shape=shape, seed=seed, scale=scale)
+        meta[f"synth_{shape}_s{seed}_d300_D50"]["synth"] = dict(shape=shape, seed=seed, scale=scale)
+    json.dump(meta, open(os.path.join(out, "cases.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["test_dataset"]
     if not mo.have_ref():
         sys.exit("oracle/_ref not built (run oracle/build_ref.sh in the build container)")
     if "test_dataset" in what:
         gen_test_dataset()
+    if "builder" in what:
+        gen_builder()
     if "kat" in what:
         from oracle import gen_kat
         gen_kat.main()
