@@ -171,6 +171,25 @@ int mm_annotation_intervals(const mm_annotation *a, const int32_t **chr, const i
                             const uint8_t **type, const uint8_t **strand);
 int mm_index_from_annotation(mm_index **out, const mm_annotation *a, int device, int bin_shift);
 
+/* ---- reads decoder (host): BAM / SAM -> tuples in file order.  Replaces Reader / SamReader / BamReader and
+ * Read::parseCigar (mmannot.cpp:846-903, 1339-1650), including XA alternative hits (mmannot.cpp:1360-1399, 1412-1422). */
+typedef struct mm_reader mm_reader;
+enum { MM_FMT_AUTO = 0, MM_FMT_SAM = 1, MM_FMT_BAM = 2 };
+/* XamRecord::setFlags ignores its argument in v1.1 (mmannot.cpp:606-609), so a verbatim run treats every record as '+'
+ * or every record as '-' depending on stack garbage.  NONE = intended meaning (flag 0x10). */
+enum { MM_STRAND_COMPAT_NONE = 0, MM_STRAND_COMPAT_PLUS = 1, MM_STRAND_COMPAT_MINUS = 2 };
+int mm_reader_open(mm_reader **out, const char *path, int format, const mm_annotation *an, int strand_compat,
+                   int unique_only /* -y unique: reads with NH != 1 never reach scan(), so they raise no chromosome warning */,
+                   int keep_names /* keep qid -> name (needed by -m) */);
+const char *mm_reader_error(const mm_reader *r);
+/* Reader::gotoNextRead x cap: fills up to cap tuples; *n = 0 at end of file */
+int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t cap, size_t *n);
+uint64_t mm_reader_qid_bound(const mm_reader *r);
+uint64_t mm_reader_n_reads(const mm_reader *r);       /* the "lines read" counter of Counter::read, mmannot.cpp:1782 */
+const char *mm_reader_name(const mm_reader *r, uint32_t qid);
+const char *mm_reader_take_log(mm_reader *r);         /* stderr text produced since the last call */
+void mm_reader_close(mm_reader *r);
+
 /* ---- synthetic workload generators for bench.py / tests (device kernels, counter-based RNG;
  * tests/synth_ref.py holds the numpy twin).  See DESIGN.md "Synthetic inputs". */
 typedef struct mm_synth_params {

@@ -82,6 +82,14 @@ SYMBOLS = {
     "mm_annotation_elements": (C.c_int, [C.c_void_p, C.POINTER(Elements)]),
     "mm_annotation_intervals": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     "mm_index_from_annotation": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "mm_reader_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mm_reader_error": (C.c_char_p, [C.c_void_p]),
+    "mm_reader_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mm_reader_qid_bound": (C.c_uint64, [C.c_void_p]),
+    "mm_reader_n_reads": (C.c_uint64, [C.c_void_p]),
+    "mm_reader_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "mm_reader_take_log": (C.c_char_p, [C.c_void_p]),
+    "mm_reader_close": (None, [C.c_void_p]),
     "mm_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(SynthParams), C.c_void_p]),
 }
 

@@ -343,3 +343,62 @@ class Annotation:
             self.close()
         except Exception:
             pass
+
+
+class ReadsDecoder:
+    """Reader / SamReader / BamReader (mmannot.cpp:1339-1650): file -> mm_aln tuples + NH, in file order."""
+    FORMATS = {None: 0, "auto": 0, "sam": 1, "bam": 2}
+
+    def __init__(self, path: str, annotation: Optional[Annotation] = None, fmt=None, strand_compat: int = 0,
+                 unique_only: bool = False, keep_names: bool = False):
+        h = C.c_void_p()
+        rc = lib().mm_reader_open(C.byref(h), path.encode(), self.FORMATS[fmt], annotation._h if annotation is not None else None,
+                                  strand_compat, 1 if unique_only else 0, 1 if keep_names else 0)
+        self._h = h
+        if rc != 0:
+            msg = lib().mm_reader_error(h).decode(errors="replace")
+            self.close()
+            raise _lib.MMError(rc, msg)
+
+    def next(self, cap: int = 1 << 20):
+        aln = np.empty(cap, dtype=ALN_DTYPE)
+        nh = np.empty(cap, dtype=np.uint32)
+        n = C.c_size_t(0)
+        rc = lib().mm_reader_next(self._h, aln.ctypes.data, nh.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise _lib.MMError(rc, lib().mm_reader_error(self._h).decode(errors="replace"))
+        return aln[:n.value], nh[:n.value]
+
+    def read_all(self, cap: int = 1 << 20):
+        al, nl = [], []
+        while True:
+            a, h = self.next(cap)
+            if len(a) == 0:
+                break
+            al.append(a.copy()); nl.append(h.copy())
+        if not al:
+            return np.empty(0, dtype=ALN_DTYPE), np.empty(0, dtype=np.uint32)
+        return np.concatenate(al), np.concatenate(nl)
+
+    def qid_bound(self) -> int:
+        return int(lib().mm_reader_qid_bound(self._h))
+
+    def n_reads(self) -> int:
+        return int(lib().mm_reader_n_reads(self._h))
+
+    def name(self, qid: int) -> str:
+        return lib().mm_reader_name(self._h, qid).decode(errors="replace")
+
+    def take_log(self) -> str:
+        return lib().mm_reader_take_log(self._h).decode(errors="replace")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mm_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,347 @@
+// cli_main.cpp — `mmannot-amd`: same command line, count table and stderr statistics as `mmannot` v1.1
+// (main, mmannot.cpp:1931-2149), with the overlap-and-count path running on the GPU through the C ABI.
+// Host work kept here: argv, file names, printing.  -m (per-read statistics, incl. the -e rescue that only
+// acts together with -m) is the reference's "slow" side channel: the per-hit element sets come
+// back from the device and the multiset bookkeeping of printReadStats/rescue (mmannot.cpp:474-509) is done here.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "mmannot_amd.h"
+
+static const char VERSION[] = "1.1";
+
+static std::string commas(uint64_t v) {
+  std::string d = std::to_string(v), o;
+  for (size_t i = 0; i < d.size(); ++i) {
+    if (i && (d.size() - i) % 3 == 0) o += ',';
+    o += d[i];
+  }
+  return o;
+}
+
+static void usage(float overlap, unsigned up, unsigned down, float rescue, unsigned threads) {
+  std::cerr << "Usage: mmannot [options]\n"
+            << "\tCompulsory options:\n"
+            << "\t\t-a file: annotation file in GTF format\n"
+            << "\t\t-r file1 [file2 ...]: reads in BAM/SAM format\n"
+            << "\tMain options:\n"
+            << "\t\t-o output: output file (default: stdout)\n"
+            << "\t\t-c config_file: configuration file (default: config.txt)\n"
+            << "\t\t-n name1 name2...: short name for each of the reads files\n"
+            << "\t\t-s strand: string (U, F, R, FR, RF, FF, defaut: F) (use several strand types if the library strategies differ)\n"
+            << "\t\t-f format (SAM or BAM): format of the read files (default: guess from file extension)\n"
+            << "\t\t-l integer: overlap type (<0: read is included, <1: % overlap, otherwise: # nt, default: " << overlap << ")\n"
+            << "\t\t-d integer: upstream region size (default: " << up << ")\n"
+            << "\t\t-D integer: downstream region size (default: " << down << ")\n"
+            << "\t\t-y string: quantification strategy, valid values are: default, unique, random, ratio (default: default)\n"
+            << "\t\t-e integer: attribute a read to a feature if at least N% of the hits map to the feature (default: "
+            << static_cast<unsigned int>(rescue * 100) << "%)\n"
+            << "\tOutput options:\n"
+            << "\t\t-p: print progress\n"
+            << "\t\t-m file: print mapping statistics for each read (slow, only work with 1 input file)\n"
+            << "\t\t-M file: print mapping statistics for each interval (slow, only work with 1 input file)\n"
+            << "\t\t-t integer: # threads (default: " << threads << ")\n"
+            << "\t\t-h: this help" << std::endl;
+}
+
+// printStats, mmannot.cpp:139-143 (numbers under the ',' grouping locale of mmannot.cpp:111-115)
+static std::string stat_line(uint64_t n, const char *label, uint64_t total) {
+  unsigned size = (unsigned) (std::log10((double) total) + 1);
+  size += (unsigned) (size / 3.0);
+  std::string num = commas(n);
+  while (num.size() < size) num = " " + num;
+  char pc[64];
+  snprintf(pc, sizeof pc, "%5.1f", (double) ((float) n / total * 100));
+  return std::string("\t") + label + num + " (" + pc + "%)\n";
+}
+
+struct PendingRead {  // readCounts + rawCounts entry, mmannot.cpp:1656-1657
+  uint32_t remaining, raw;
+  std::vector<uint8_t> regions;
+};
+
+int main(int argc, char **argv) {
+  float overlap = -1.0f, rescue_threshold = 1.0f;
+  bool use_rescue = false;
+  int strandedness = MM_STRANDED_F, strategy = MM_STRAT_DEFAULT, format = MM_FMT_AUTO, strand_compat = MM_STRAND_COMPAT_NONE;
+  unsigned upstream = 1000, downstream = 1000, n_threads = 1;
+  bool progress = false;
+  int device = 0;
+  std::string gtf, output, config = "config.txt", read_stats_file, interval_stats_file;
+  std::vector<std::string> reads, names;
+  if (argc == 1) { usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_SUCCESS; }
+  for (int i = 1; i < argc; i++) {
+    std::string s(argv[i]);
+    if (s.empty()) continue;
+    auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : (++i, ""); };
+    if (s == "-a") gtf = next();
+    else if (s == "-r") { for (++i; i < argc; ++i) { std::string t(argv[i]); if (t[0] == '-') { --i; break; } reads.push_back(t); } }
+    else if (s == "-n") { for (++i; i < argc; ++i) { std::string t(argv[i]); if (t[0] == '-') { --i; break; } names.push_back(t); } }
+    else if (s == "-c") config = next();
+    else if (s == "-o") output = next();
+    else if (s == "-l") overlap = std::stof(next());
+    else if (s == "-s") {
+      for (++i; i < argc; ++i) {
+        s = argv[i];
+        if (s == "U") strandedness = MM_STRANDED_U;
+        else if (s == "F") strandedness = MM_STRANDED_F;
+        else if (s == "R") strandedness = MM_STRANDED_R;
+        else if (s[0] == '-' || s.empty()) { --i; break; }
+        else {
+          std::cerr << "Do not understand strandedness " << s << "\n" << "Exiting." << std::endl;
+          usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+          return EXIT_FAILURE;
+        }
+      }
+    }
+    else if (s == "-p") progress = true;
+    else if (s == "-t") n_threads = (unsigned) std::stoi(next());
+    else if (s == "-m") read_stats_file = next();
+    else if (s == "-M") interval_stats_file = next();
+    else if (s == "-f") {
+      for (++i; i < argc; ++i) {
+        s = argv[i];
+        std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        if (s == "sam") format = MM_FMT_SAM;
+        else if (s == "bam") format = MM_FMT_BAM;
+        else if (s.empty() || s[0] == '-') { --i; break; }
+        else {
+          std::cerr << "Do not understand reads format " << s << "\n" << "Exiting." << std::endl;
+          usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+          return EXIT_FAILURE;
+        }
+      }
+    }
+    else if (s == "-e") { rescue_threshold = std::stof(next()) / 100.0f; if (rescue_threshold < 1.0) use_rescue = true; }
+    else if (s == "-d") upstream = (unsigned) std::stoul(next());
+    else if (s == "-D") downstream = (unsigned) std::stoul(next());
+    else if (s == "-y") {
+      s = next();
+      std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+      if (s == "default") strategy = MM_STRAT_DEFAULT;
+      else if (s == "unique") strategy = MM_STRAT_UNIQUE;
+      else if (s == "random") strategy = MM_STRAT_RANDOM;
+      else if (s == "ratio") strategy = MM_STRAT_RATIO;
+      else {
+        std::cerr << "Do not understand strategy " << s << "\n" << "Exiting." << std::endl;
+        usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+        return EXIT_FAILURE;
+      }
+    }
+    else if (s == "-v") { std::cerr << "mmannot v" << VERSION << std::endl; return EXIT_SUCCESS; }
+    else if (s == "-h") { usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_SUCCESS; }
+    // extensions (not in the reference): device selection and the verbatim-strand compatibility switch
+    else if (s == "--device") device = std::stoi(next());
+    else if (s == "--compat-strand") {
+      s = next();
+      if (s == "plus" || s == "const1") strand_compat = MM_STRAND_COMPAT_PLUS;
+      else if (s == "minus" || s == "const0") strand_compat = MM_STRAND_COMPAT_MINUS;
+      else strand_compat = MM_STRAND_COMPAT_NONE;
+    }
+    else {
+      std::cerr << "Error: wrong parameter '" << s << "'.\nExiting." << std::endl;
+      usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+      return EXIT_FAILURE;
+    }
+  }
+  if (gtf.empty()) { std::cerr << "Missing input GTF file.\nExiting." << std::endl; usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_FAILURE; }
+  if (reads.empty()) { std::cerr << "Missing input BAM file.\nExiting." << std::endl; usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_FAILURE; }
+  const size_t n_inputs = reads.size();
+  if (names.empty()) {
+    for (const std::string &f : reads) {
+      std::string n = f;
+      size_t p = n.find_last_of("/");
+      if (p != std::string::npos) n = n.substr(p + 1);
+      p = n.find_last_of(".");
+      if (p != std::string::npos) n = n.substr(0, p);
+      names.push_back(n);
+    }
+  } else if (names.size() != n_inputs) {
+    std::cerr << "Number of names is not equal to number of file names.\nExiting." << std::endl;
+    usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+    return EXIT_FAILURE;
+  }
+  const bool read_stats = !read_stats_file.empty(), interval_stats = !interval_stats_file.empty();
+  if ((read_stats || interval_stats) && n_inputs != 1) {
+    std::cerr << "Only one reads file when providing reads or interval statistics.\nExiting." << std::endl;
+    usage(overlap, upstream, downstream, rescue_threshold, n_threads);
+    return EXIT_FAILURE;
+  }
+  if (interval_stats) { std::cerr << "mmannot-amd: -M (per-interval statistics) is not implemented yet.\nExiting." << std::endl; return EXIT_FAILURE; }
+  if (strategy == MM_STRAT_RANDOM) {
+    std::cerr << "mmannot-amd: -y random replays libc rand() in file order and is not a device strategy.\nExiting." << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::ofstream of, read_stats_out;
+  if (!output.empty()) of.open(output.c_str());
+  std::ostream &out = output.empty() ? std::cout : of;
+  if (read_stats) read_stats_out.open(read_stats_file.c_str());
+
+  mm_annotation *an = nullptr;
+  if (mm_annotation_load(&an, config.c_str(), gtf.c_str(), upstream, downstream) != MM_OK) {
+    std::cerr << mm_annotation_error() << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::cerr << mm_annotation_log(an);
+  mm_index *index = nullptr;
+  if (mm_index_from_annotation(&index, an, device, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+  mm_options opt;
+  opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
+  opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = read_stats ? 1 : 0;
+  mm_ctx *ctx = nullptr;
+  if (mm_ctx_create(&ctx, index, &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+  const int32_t E = mm_annotation_n_elements(an);
+  std::vector<std::string> elem_names;
+  for (int32_t e = 0; e < E; ++e) elem_names.push_back(mm_annotation_element_name(an, e));
+
+  std::map<uint64_t, std::vector<unsigned>> table;  // element set -> one column per input (TableCount::regionCounts, :1858)
+  const size_t BATCH = 1 << 22;
+  std::vector<mm_aln> aln(BATCH);
+  std::vector<uint32_t> nh(BATCH);
+  std::vector<uint64_t> hm;
+  for (size_t fi = 0; fi < n_inputs; ++fi) {
+    if (mm_reset(ctx) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    mm_reader *rd = nullptr;
+    int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
+    if (rc != MM_OK) { std::cerr << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+    // -m bookkeeping (host): the multiset of element ids per pending read
+    std::unordered_map<uint32_t, PendingRead> pending;
+    std::map<uint64_t, double> host_counts;
+    uint64_t h_reads = 0, h_rescued = 0;
+    auto print_read_stats = [&](uint32_t qid, unsigned nhits, std::vector<uint8_t> &regions) -> void {  // :474-493 + rescue :497-509
+      std::sort(regions.begin(), regions.end());
+      read_stats_out << mm_reader_name(rd, qid) << " \t" << nhits;
+      for (size_t a = 0; a < regions.size();) {
+        size_t b = a;
+        while (b < regions.size() && regions[b] == regions[a]) ++b;
+        read_stats_out << "\t" << elem_names[regions[a]] << ": " << (b - a);
+        a = b;
+      }
+      bool rescued = false;
+      if (use_rescue && regions.size() != 1) {
+        const size_t n = regions.size();
+        const size_t t = (size_t) std::ceil(n * rescue_threshold);
+        std::vector<size_t> c((size_t) E, 0);
+        for (uint8_t r : regions) if (++c[r] >= t) { regions.assign(1, r); rescued = true; break; }
+      }
+      if (rescued) read_stats_out << "\tRescued";
+      read_stats_out << "\n";
+    };
+    auto count_regions = [&](std::vector<uint8_t> &regions, double w) -> size_t {
+      uint64_t m = 0;
+      for (uint8_t r : regions) m |= 1ull << r;
+      host_counts[m] += w;
+      return (size_t) __builtin_popcountll(m);
+    };
+    uint64_t cpt = 0;
+    for (;;) {
+      size_t n = 0;
+      rc = mm_reader_next(rd, aln.data(), nh.data(), BATCH, &n);
+      std::cerr << mm_reader_take_log(rd);
+      if (rc != MM_OK) { std::cerr << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+      if (n == 0) break;
+      if (mm_annotate_batch(ctx, aln.data(), nh.data(), n, mm_reader_qid_bound(rd), 0) != MM_OK || mm_sync(ctx) != MM_OK) {
+        std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
+      }
+      if (read_stats) {
+        hm.resize(n);
+        if (mm_get_hit_masks(ctx, hm.data(), n) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        for (size_t i = 0; i < n; ++i) {
+          if (hm[i] == ~0ull) continue;            // skipped by -y unique
+          std::vector<uint8_t> regions;
+          for (int e = 0; e < E; ++e) if (hm[i] >> e & 1) regions.push_back((uint8_t) e);
+          const uint32_t q = aln[i].qid, h = nh[i];
+          if (h > 1 && strategy == MM_STRAT_DEFAULT) {   // :1669-1702
+            auto it = pending.find(q);
+            if (it == pending.end()) { pending[q] = PendingRead{h - 1, h, regions}; ++h_reads; }
+            else {
+              PendingRead &p = it->second;
+              --p.remaining;
+              p.regions.insert(p.regions.end(), regions.begin(), regions.end());
+              if (p.remaining == 0) {
+                if (!p.regions.empty()) {
+                  print_read_stats(q, h, p.regions);
+                  if (count_regions(p.regions, 1.0) == 1) ++h_rescued;
+                }
+                pending.erase(it);
+              }
+            }
+          } else {                                       // :1703-1738
+            if (!regions.empty()) {
+              print_read_stats(q, h, regions);
+              count_regions(regions, strategy == MM_STRAT_RATIO ? 1.0 / h : 1.0);
+            }
+            ++h_reads;
+          }
+        }
+      }
+      cpt += n;
+      if (progress && n_threads == 1) std::cerr << "\t" << commas(cpt) << " lines read.\r" << std::flush;
+    }
+    std::cerr << "\t" << commas(mm_reader_n_reads(rd)) << " lines read, done." << std::endl;
+    if (mm_finalize(ctx) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    uint64_t st[MM_N_STATS];
+    mm_get_stats(ctx, st);
+    std::vector<uint64_t> masks;
+    std::vector<double> sums;
+    if (read_stats) {
+      for (auto &e : pending) {                          // EOF flush :1783-1792
+        if (e.second.regions.empty()) continue;
+        print_read_stats(e.first, e.second.raw, e.second.regions);
+        if (count_regions(e.second.regions, 1.0) == 1 && e.second.raw > 1) ++h_rescued;
+      }
+      st[MM_STAT_READS] = h_reads; st[MM_STAT_RESCUED] = h_rescued;
+      for (auto &e : host_counts) { masks.push_back(e.first); sums.push_back(e.second); }
+    } else {
+      size_t nr = 0;
+      mm_get_rows(ctx, nullptr, nullptr, 0, &nr);
+      masks.resize(nr); sums.resize(nr);
+      if (nr && mm_get_rows(ctx, masks.data(), sums.data(), nr, &nr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    }
+    // Counter::dump, :1806-1818
+    std::cerr << "Results for " << reads[fi] << ":" << std::endl;
+    if (st[MM_STAT_HITS] == 0) std::cerr << "\tNo hit." << std::endl;
+    else {
+      std::cerr << "\t# reads:                       " << commas(st[MM_STAT_READS]) << "\n"
+                << stat_line(st[MM_STAT_UNIQUE], "# uniquely mapped reads:       ", st[MM_STAT_READS])
+                << stat_line(st[MM_STAT_RESCUED], "# multi-mapping rescued reads: ", st[MM_STAT_READS])
+                << "\t# hits:                        " << commas(st[MM_STAT_HITS]) << "\n"
+                << stat_line(st[MM_STAT_AMBIGUOUS], "# ambiguous hits:              ", st[MM_STAT_HITS])
+                << stat_line(st[MM_STAT_UNASSIGNED], "# unassigned hits:             ", st[MM_STAT_HITS]);
+    }
+    for (size_t r = 0; r < masks.size(); ++r) {          // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
+      auto &col = table[masks[r]];
+      if (col.empty()) col.assign(n_inputs, 0);
+      col[fi] = mm_round_to_uint(sums[r]);
+    }
+    mm_reader_close(rd);
+  }
+  // TableCount::dump, :1877-1900
+  std::vector<uint64_t> keys;
+  for (auto &e : table) keys.push_back(e.first);
+  mm_sort_rows(keys.data(), nullptr, keys.size());
+  out << "Type";
+  for (const std::string &s : names) out << "\t" << s;
+  out << "\n";
+  for (uint64_t k : keys) {
+    bool first = true;
+    for (int e = 0; e < E; ++e) if (k >> e & 1) { out << (first ? "" : "--") << elem_names[e]; first = false; }
+    for (unsigned v : table[k]) out << "\t" << v;
+    out << "\n";
+  }
+  out.flush();
+  if (read_stats) read_stats_out.close();
+  mm_ctx_destroy(ctx); mm_index_destroy(index); mm_annotation_free(an);
+  std::cerr << "Successfully done." << std::endl;
+  return 0;
+}

@@ -305,7 +305,7 @@ extern "C" int mm_annotation_load(mm_annotation **out, const char *config_path, 
   if (!err.empty()) { g_annot_err = err; delete A; return MM_ERR_PARSE; }
   const ConfigModel &C = A->cfg;
   std::ifstream f(gtf_path);
-  if (!f.good()) { g_annot_err = std::string("Error, Annotation file '") + gtf_path + "' does not exists!"; delete A; return MM_ERR_IO; }
+  if (!f.good()) { g_annot_err = A->log + "Error, Annotation file '" + gtf_path + "' does not exists!"; delete A; return MM_ERR_IO; }
   A->log += "Reading GTF file\n";
   std::unordered_map<std::string, size_t> gene_of;  // any id (gene, transcript, ...) -> gene index; reset per chromosome block
   std::unordered_set<std::string> unused;
