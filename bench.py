@@ -89,8 +89,8 @@ def main():
     torch.cuda.synchronize()
     groups_per_tuple = (nh_max / (nh_max * (nh_max + 1) / 2.0)) if nh_max > 1 else 1.0
 
-    def qid_bound(step):  # exclusive bound of the read-name ids of batches 0..step
-        return int((step + 1) * B * groups_per_tuple) + nh_max + 2
+    def qid_bound(step):  # exclusive bound of the read-name ids of the whole stream (known up front here; a larger bound is allowed)
+        return int(nb * B * groups_per_tuple) + nh_max + 2
 
     def run_step(s):
         ctr.add_batch_device(alns[s].data_ptr(), nhs[s].data_ptr() if nhs[s] is not None else None, B, qid_bound(s))

@@ -48,8 +48,28 @@ extern "C" const char *mm_version(void) { return MM_VERSION; }
 
 // ----------------------------------------------------------------------------- device structures
 #define GT_CAP (1u << 16)          // global element-set table (distinct rows of the count table)
-#define LT_CAP 256u                // per-workgroup LDS table
+#define LT_CAP 1024u               // per-workgroup LDS table
+#define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
+
+// per-batch scalars kept on the device (no host round trip between the kernels of one batch)
+enum { INFO_M = 0,      // number of records in the grouping pipeline
+       INFO_QINV = 1,   // max over ~qid of the multi-hit records = ~(smallest qid)
+       INFO_QMAX = 2,   // largest qid of the multi-hit records
+       INFO_BIGNH = 3,  // some multi-hit record has NH >= 65535: payloads carry the record index instead of (slot, NH)
+       INFO_WORDS = 4 };
+
+__host__ __device__ inline int bits_for_range(unsigned int span) {  // bits needed for keys in [0, span]
+  int b = 1;
+  while (b < 32 && (1ull << b) <= (unsigned long long) span) ++b;
+  return b;
+}
+// sort-key width of this batch: multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys)
+__device__ __forceinline__ int batch_key_bits(const unsigned int *info, int fixed_bits) {
+  if (fixed_bits) return fixed_bits;
+  const unsigned int qmin = ~info[INFO_QINV], qmax = info[INFO_QMAX];
+  return qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
+}
 
 struct GlobalTable {
   u64 *key;      // 0 = empty (an element set is never empty)
@@ -62,9 +82,7 @@ struct ProbeParams {
   const int4 *iv;          // {start, end, type | F<<8, exclusive prefix max of end within the chromosome}
   const int4 *act;         // same record format
   const uint2 *bins;       // per chromosome nbins+1 entries {first, actOff}
-  const u32 *chrBinBase;
-  const u32 *chrNBins;
-  const u32 *chrIvEnd;
+  const uint4 *chrInfo;     // per chromosome {first bin record, number of bins, end of its interval range, 0}
   u32 nchr;
   u32 shift;
   u64 elemF, elemR, elemUp, elemDown;  // bit e set: element e is declared '+', '-', is "upstream", is "downstream"
@@ -84,15 +102,16 @@ __device__ __forceinline__ u32 hash64(u64 k) {
 struct LdsTable {
   u64 key[LT_CAP];
   u32 cnt[LT_CAP];
+  u32 slot[LT_CAP];   // cached slot of the set in the global table (NO_KEY = not looked up yet)
 };
 
 __device__ __forceinline__ void lds_table_init(LdsTable &t) {
-  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; }
+  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; t.slot[i] = NO_KEY; }
 }
 
 __device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
   u32 h = hash64(m) & (LT_CAP - 1);
-  for (u32 p = 0; p < LT_CAP; ++p) {
+  for (u32 p = 0; p < LT_MAXPROBE; ++p) {
     u64 k = *(volatile u64 *) &t.key[h];
     if (k == 0) {
       k = atomicCAS(&t.key[h], 0ull, m);
@@ -102,6 +121,27 @@ __device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
     h = (h + 1) & (LT_CAP - 1);
   }
   return false;
+}
+
+__device__ __forceinline__ u32 gt_find_or_insert(const struct GlobalTable &g, u64 m);
+
+// slot of set m in the global table, through the workgroup's LDS table (one global lookup per set and workgroup)
+__device__ __forceinline__ u32 lds_cached_slot(LdsTable &t, const struct GlobalTable &g, u64 m) {
+  u32 h = hash64(m) & (LT_CAP - 1);
+  for (u32 p = 0; p < LT_MAXPROBE; ++p) {
+    u64 k = *(volatile u64 *) &t.key[h];
+    if (k == 0) {
+      k = atomicCAS(&t.key[h], 0ull, m);
+      if (k == 0) k = m;
+    }
+    if (k == m) {
+      u32 sl = *(volatile u32 *) &t.slot[h];
+      if (sl == NO_KEY) { sl = gt_find_or_insert(g, m); t.slot[h] = sl; }
+      return sl;
+    }
+    h = (h + 1) & (LT_CAP - 1);
+  }
+  return gt_find_or_insert(g, m);
 }
 
 // returns slot or NO_KEY when full (error flag raised)
@@ -127,8 +167,13 @@ __device__ __forceinline__ void gt_add(const GlobalTable &g, u64 m, u64 inc) {
 
 __device__ __forceinline__ void lds_table_flush(LdsTable &t, const GlobalTable &g) {
   for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) {
-    u64 k = t.key[i];
-    if (k) gt_add(g, k, (u64) t.cnt[i]);
+    const u64 k = t.key[i];
+    const u32 c = t.cnt[i];
+    if (k && c) {
+      const u32 sl = t.slot[i];
+      if (sl != NO_KEY) atomicAdd(&g.cnt[sl], (u64) c);
+      else gt_add(g, k, (u64) c);
+    }
   }
 }
 
@@ -179,14 +224,14 @@ struct Cand {
 
 __device__ __forceinline__ bool locate(const ProbeParams &P, u32 tid1, int s, Cand &c) {
   if (tid1 == 0 || tid1 > P.nchr) return false;    // chromosome unknown to the annotation (mmannot.cpp:1293-1302)
-  const u32 ch = tid1 - 1;
-  const u32 nb = P.chrNBins[ch];
+  const uint4 ci = P.chrInfo[tid1 - 1];
+  const u32 nb = ci.y;
   if (nb == 0) return false;                       // chromosome without any interval: not in `bins` either
   u32 b = (u32) s >> P.shift;
   b = min(b, nb - 1);
-  const uint2 *B = P.bins + P.chrBinBase[ch] + b;
+  const uint2 *B = P.bins + ci.x + b;
   const uint2 b0 = B[0];
-  c.a0 = b0.y; c.a1 = B[1].y; c.i0 = b0.x; c.i1 = P.chrIvEnd[ch];
+  c.a0 = b0.y; c.a1 = B[1].y; c.i0 = b0.x; c.i1 = ci.z;
   return true;
 }
 
@@ -218,18 +263,35 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
   Cand c;
   if (!locate(P, tid1, s, c)) return 0;
   u64 hit = 0;
-  for (u32 k = c.a0; k < c.a1; ++k) {
-    const int4 r = P.act[k];
-    u32 o;
-    if (iv_pass<OVL>(P, r, s, e, rstrand, o)) hit |= 1ull << ((u32) r.z & 0xffu);
+  u32 o;
+  // The loads are issued ahead of their use so that one memory round trip serves most reads: the first two
+  // sorted-range records are requested together with the active list (a read rarely sees more than two).
+  const int4 none = make_int4(0x7fffffff, 0, 0, 0);
+  u32 i = c.i0;
+  int4 f0 = (i < c.i1) ? P.iv[i] : none;
+  int4 f1 = (i + 1 < c.i1) ? P.iv[i + 1] : none;
+  u32 k = c.a0;
+  for (; k + 1 < c.a1; k += 2) {
+    const int4 r0 = P.act[k], r1 = P.act[k + 1];
+    if (iv_pass<OVL>(P, r0, s, e, rstrand, o)) hit |= 1ull << ((u32) r0.z & 0xffu);
+    if (iv_pass<OVL>(P, r1, s, e, rstrand, o)) hit |= 1ull << ((u32) r1.z & 0xffu);
+    walked += 2;
+  }
+  if (k < c.a1) {
+    const int4 r0 = P.act[k];
+    if (iv_pass<OVL>(P, r0, s, e, rstrand, o)) hit |= 1ull << ((u32) r0.z & 0xffu);
     ++walked;
   }
-  for (u32 i = c.i0; i < c.i1; ++i) {
-    const int4 r = P.iv[i];
-    if (r.x > e) break;                            // isAfter, mmannot.cpp:1311
-    u32 o;
-    if (iv_pass<OVL>(P, r, s, e, rstrand, o)) hit |= 1ull << ((u32) r.z & 0xffu);
+  for (;;) {
+    if (f0.x > e) break;                           // isAfter, mmannot.cpp:1311 (also the end-of-chromosome sentinel)
+    if (iv_pass<OVL>(P, f0, s, e, rstrand, o)) hit |= 1ull << ((u32) f0.z & 0xffu);
     ++walked;
+    if (f1.x > e) break;
+    if (iv_pass<OVL>(P, f1, s, e, rstrand, o)) hit |= 1ull << ((u32) f1.z & 0xffu);
+    ++walked;
+    i += 2;
+    f0 = (i < c.i1) ? P.iv[i] : none;
+    f1 = (i + 1 < c.i1) ? P.iv[i + 1] : none;
   }
   if (!hit) return 0;
   // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
@@ -261,13 +323,17 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
 //   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
 template <int OVL>
 __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const u32 *__restrict__ nhp,
-                                               size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, GlobalTable G,
-                                               u64 *__restrict__ stats, u64 *__restrict__ walkstat) {
+                                               size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
+                                               u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
+                                               u64 *__restrict__ walkstat) {
   __shared__ LdsTable T;
   __shared__ u32 sstat[8];
+  __shared__ u32 sq[3];   // max(~qid) = ~min, max(qid), saw NH >= 0xFFFF
   lds_table_init(T);
   if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
+  if (threadIdx.x < 3) sq[threadIdx.x] = 0;
   __syncthreads();
+  u32 qinv = 0, qmax = 0, big = 0;
   const u32 lane = threadIdx.x & 63;
   u32 cHits = 0, cReads = 0, cUnique = 0, cAmb = 0, cMulti = 0, cUnas = 0;  // wave-uniform
   u32 walked = 0;
@@ -298,31 +364,47 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
     cMulti += __popcll(__ballot(grouped));
     cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
     const bool counted = processed && !grouped && mask != 0;                       // mmannot.cpp:1704
-    u32 key = NO_KEY;
-    if (grouped) key = (u32) a.w;
-    // wave aggregation over equal element sets
-    bool active = counted;
+    u32 key = NO_KEY, pay = 0xFFFFu;
+    if (grouped) {
+      key = (u32) a.w;
+      qinv = max(qinv, ~key); qmax = max(qmax, key);
+      if (nh >= 0xFFFFu) big = 1;
+    }
+    // wave aggregation over equal element sets: one table operation per distinct set and wave.
+    //   per-hit branch (default/unique): the set is counted now (LDS table);
+    //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
+    //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
+    const bool want_slot = (ratio && counted) || (grouped && mask != 0);
+    bool active = counted || want_slot;
     u64 bal;
     while ((bal = __ballot(active)) != 0) {
       const int leader = __ffsll((long long) bal) - 1;
       const u64 m = __shfl(mask, leader);
       const bool same = active && (mask == m);
-      const u64 sb = __ballot(same);
-      if (ratio) {
-        u32 slot = 0;
-        if ((int) lane == leader) slot = gt_find_or_insert(G, m);
+      const u64 cb = __ballot(same && counted && !ratio);
+      const u64 wb = __ballot(same && want_slot);
+      u32 slot = 0;
+      if ((int) lane == leader) {
+        if (cb) { const u32 c = (u32) __popcll(cb); if (!lds_table_add(T, m, c)) gt_add(G, m, c); }
+        if (wb) slot = lds_cached_slot(T, G, m);
+      }
+      if (wb) {
         slot = __shfl(slot, leader);
-        if (same) key = slot;
-      } else if ((int) lane == leader) {
-        const u32 c = (u32) __popcll(sb);
-        if (!lds_table_add(T, m, c)) gt_add(G, m, c);
+        if (same && want_slot) { if (ratio) key = slot; else pay = slot & 0xFFFFu; }
       }
       active = active && !same;
     }
     if (valid) {
-      if (gkey) gkey[i] = key;
+      if (gkey) {
+        gkey[i] = key;
+        gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
+      }
       if (hm && (P.keep || grouped)) hm[i] = processed ? mask : ~0ull;
     }
+  }
+  if (grouped_strategy && gkey) {
+    for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); big |= __shfl_down(big, off); }
+    if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (big) atomicOr(&sq[2], 1u); }
   }
   if (lane == 0) {
     atomicAdd(&sstat[MM_STAT_HITS], cHits); atomicAdd(&sstat[MM_STAT_READS], cReads);
@@ -337,6 +419,11 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
   }
   __syncthreads();
   if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
+  if (grouped_strategy && gkey && threadIdx.x == 0) {
+    if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
+    if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
+    if (sq[2]) atomicOr(&info[INFO_BIGNH], 1u);
+  }
   lds_table_flush(T, G);
 }
 
@@ -389,7 +476,8 @@ __global__ __launch_bounds__(1024) void k_scan_single(u32 *__restrict__ a, u32 n
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict__ gkey, size_t n, const u32 *__restrict__ tileOff,
+__global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict__ gkey, const u32 *__restrict__ gpay, size_t n,
+                                                           const u32 *__restrict__ tileOff, const u32 *__restrict__ info, int rebase,
                                                            u32 *__restrict__ keys, u32 *__restrict__ vals) {
   __shared__ u32 wcnt[4];
   __shared__ u32 run;
@@ -397,6 +485,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict
   __syncthreads();
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u32 qmin = rebase ? ~info[INFO_QINV] : 0u;
+  const bool by_index = rebase && info[INFO_BIGNH];
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
     u32 k = NO_KEY;
@@ -408,7 +498,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict
     __syncthreads();
     u32 off = run;
     for (u32 q = 0; q < w; ++q) off += wcnt[q];
-    if (f) { keys[off + rank] = k; vals[off + rank] = (u32) i; }
+    if (f) { keys[off + rank] = k - qmin; vals[off + rank] = by_index ? (u32) i : gpay[i]; }
     __syncthreads();
     if (threadIdx.x == 0) run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     __syncthreads();
@@ -416,12 +506,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict
 }
 
 // ----------------------------------------------------------------------------- stable LSD radix sort (8-bit digits)
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ Mptr, int shift,
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ info, int shift, int fixed_bits,
                                                         u32 *__restrict__ hist, u32 nblk) {
   __shared__ u32 h[256];
+  if (shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
   h[threadIdx.x] = 0;
   __syncthreads();
-  const u32 M = *Mptr;
+  const u32 M = info[INFO_M];
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   if (lo < M) {
     for (int r = 0; r < RS_ROUNDS; ++r) {
@@ -434,9 +525,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 }
 
 // one workgroup per digit: exclusive scan of its row of per-tile counts
-__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal) {
+__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal,
+                                                      const u32 *__restrict__ info, int shift, int fixed_bits) {
   __shared__ u32 wsum[4];
   __shared__ u32 carry;
+  if (shift >= batch_key_bits(info, fixed_bits)) return;
   u32 *row = hist + (size_t) blockIdx.x * nblk;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -462,8 +555,9 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u3
   if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal) {
+__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, const u32 *__restrict__ info, int shift, int fixed_bits) {
   __shared__ u32 s[256];
+  if (shift >= batch_key_bits(info, fixed_bits)) return;
   s[threadIdx.x] = rowTotal[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -474,25 +568,64 @@ __global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal)
   rowTotal[threadIdx.x] = s[threadIdx.x];
 }
 
+// One pass of the stable LSD sort for one tile of RS_TILE pairs.
+//   A. every wave owns a contiguous quarter of the tile, keeps its 16x64 pairs in registers and counts digits
+//      per wave in LDS;
+//   B. per-digit exclusive offsets (tile-local and global) from those counts;
+//   C. each wave ranks its pairs sub-round by sub-round (8 ballots per pair give the lanes holding the same
+//      digit) against its private running offsets - no workgroup barrier inside the loop - and drops the pairs
+//      at their tile-local sorted position in LDS;
+//   D. the sorted tile is copied out: consecutive lanes write consecutive addresses inside each digit run, so
+//      the scatter reaches memory as 64-B-and-longer segments instead of isolated 4-B stores.
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
-                                                           u32 *__restrict__ vout, const u32 *__restrict__ Mptr, int shift,
+                                                           u32 *__restrict__ vout, const u32 *__restrict__ info, int shift, int fixed_bits,
                                                            const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
-  __shared__ u32 run[256];      // next output position of digit d for this tile
-  __shared__ u32 wcnt[4][256];  // per-wave digit counts of the current round
-  const u32 M = *Mptr;
+  __shared__ u32 lkey[RS_TILE];
+  __shared__ u32 lval[RS_TILE];
+  __shared__ u32 cntw[4][256];   // A: digit counts per wave; C: running tile-local offset per wave
+  __shared__ u32 goff[256];      // global position of digit d's first pair of this tile, minus its tile-local offset
+  __shared__ u32 wsum[4];
+  if (shift >= batch_key_bits(info, fixed_bits)) return;
+  const u32 M = info[INFO_M];
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   if (lo >= M) return;
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
-  run[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x];
-  wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
+  const u32 tcount = (u32) min((size_t) RS_TILE, (size_t) M - lo);
+  cntw[0][t] = 0; cntw[1][t] = 0; cntw[2][t] = 0; cntw[3][t] = 0;
   __syncthreads();
+  u32 kreg[RS_ROUNDS], vreg[RS_ROUNDS];
+  const u32 wbase = w * (RS_TILE / 4);
+#pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
-    const size_t i = lo + (size_t) r * RS_THREADS + t;
-    const bool valid = i < M;
-    u32 k = 0, v = 0;
-    if (valid) { k = kin[i]; v = vin[i]; }
-    const u32 d = (k >> shift) & 255u;
-    // lanes of this wave holding the same digit (8 ballots)
+    const u32 li = wbase + (u32) r * 64u + lane;
+    kreg[r] = 0; vreg[r] = 0;
+    if (li < tcount) {
+      kreg[r] = kin[lo + li]; vreg[r] = vin[lo + li];
+      atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  {  // B: thread t owns digit t
+    const u32 c0 = cntw[0][t], c1 = cntw[1][t], c2 = cntw[2][t], c3 = cntw[3][t];
+    const u32 tot = c0 + c1 + c2 + c3;
+    u32 x = tot;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if ((int) lane >= off) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 loff = x - tot;
+    for (u32 q = 0; q < w; ++q) loff += wsum[q];
+    goff[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x] - loff;
+    cntw[0][t] = loff; cntw[1][t] = loff + c0; cntw[2][t] = loff + c0 + c1; cntw[3][t] = loff + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {  // C: wave-private, LDS operations of one wave execute in program order
+    const u32 li = wbase + (u32) r * 64u + lane;
+    const bool valid = li < tcount;
+    const u32 d = (kreg[r] >> shift) & 255u;
     u64 peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -500,17 +633,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
       peers &= ((d >> b) & 1u) ? bb : ~bb;
     }
     const u32 rank = (u32) __popcll(peers & ((1ull << lane) - 1));
-    if (valid && rank == 0) wcnt[w][d] = (u32) __popcll(peers);
-    __syncthreads();
-    if (valid) {
-      u32 pos = run[d] + rank;
-      for (u32 q = 0; q < w; ++q) pos += wcnt[q][d];
-      kout[pos] = k; vout[pos] = v;
-    }
-    __syncthreads();
-    run[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
-    wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
-    __syncthreads();
+    u32 pos = 0;
+    if (valid) pos = cntw[w][d] + rank;
+    if (valid && rank == 0) cntw[w][d] = pos + (u32) __popcll(peers);
+    if (valid) { lkey[pos] = kreg[r]; lval[pos] = vreg[r]; }
+  }
+  __syncthreads();
+  for (u32 i = t; i < tcount; i += RS_THREADS) {  // D
+    const u32 k = lkey[i];
+    const u32 g = goff[(k >> shift) & 255u] + i;
+    kout[g] = k; vout[g] = lval[i];
   }
 }
 
@@ -521,35 +653,105 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
 // union their element sets; at 0 the group is closed, counted (mmannot.cpp:1688) and erased, so a
 // further record of the same name opens a new group.  State (remaining, union) is carried across
 // batches in grpRem/grpU, the dense replacement of readCounts (mmannot.cpp:1656).
-__global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ skeys, const u32 *__restrict__ svals,
-                                                       const u32 *__restrict__ Mptr, const u32 *__restrict__ nhp,
-                                                       const u64 *__restrict__ hm, u32 *__restrict__ grpRem, u64 *__restrict__ grpU,
-                                                       GlobalTable G, u64 *__restrict__ stats) {
+__global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ kA, const u32 *__restrict__ vA, const u32 *__restrict__ kB,
+                                                       const u32 *__restrict__ vB, const u32 *__restrict__ info,
+                                                       const u32 *__restrict__ nhp, const u64 *__restrict__ hm, u32 *__restrict__ grpRem,
+                                                       u64 *__restrict__ grpU, GlobalTable G, u64 *__restrict__ stats) {
   __shared__ LdsTable T;
   __shared__ u32 sOpened, sRescued;
   lds_table_init(T);
   if (threadIdx.x == 0) { sOpened = 0; sRescued = 0; }
   __syncthreads();
-  const u32 M = *Mptr;
+  const u32 M = info[INFO_M];
+  const u32 qmin = ~info[INFO_QINV];
+  const bool by_index = info[INFO_BIGNH] != 0;
+  const int passes = (batch_key_bits(info, 0) + 7) / 8;       // the sort ping-pongs A -> B -> A ...
+  const u32 *__restrict__ skeys = (passes & 1) ? kB : kA;
+  const u32 *__restrict__ svals = (passes & 1) ? vB : vA;
+  const u32 lane = threadIdx.x & 63;
   u32 opened = 0, rescued = 0;
-  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
-    const u32 q = skeys[j];
-    if (j != 0 && skeys[j - 1] == q) continue;
-    u32 rem = grpRem[q];
-    u64 U = grpU[q];
-    for (size_t k = j; k < M && skeys[k] == q; ++k) {
-      const u32 i = svals[k];
-      const u64 m = hm[i];
-      if (rem == 0) {             // no pending group of this name: open one (mmannot.cpp:1672-1677)
-        rem = nhp[i] - 1; U = m; ++opened;
-      } else {                    // mmannot.cpp:1678-1701
-        --rem; U |= m;
-        if (rem == 0) {
-          if (U) {
-            if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
-            if ((U & (U - 1)) == 0) ++rescued;
-          }
-          U = 0;
+  // record k of the sorted stream -> (element set, NH)
+  auto fetch = [&](size_t k, u64 &m, u32 &nhv) {
+    const u32 pv = svals[k];
+    if (by_index) { m = hm[pv]; nhv = nhp[pv]; }
+    else { const u32 slot = pv & 0xFFFFu; m = (slot == 0xFFFFu) ? 0ull : G.key[slot]; nhv = pv >> 16; }
+  };
+  auto close_group = [&](u64 U) {
+    if (U) {
+      if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
+      if ((U & (U - 1)) == 0) ++rescued;
+    }
+  };
+  const size_t Mr = ((size_t) M + 63) & ~(size_t) 63;
+  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < Mr; j += (size_t) gridDim.x * blockDim.x) {
+    // every lane loads its own record and both neighbours' keys (coalesced); a name's records are consecutive
+    const bool valid = j < M;
+    u32 key = 0, nhv = 0, rem = 0;
+    u64 m = 0, U = 0;
+    bool head = false, last = true;
+    if (valid) {
+      key = skeys[j];
+      head = (j == 0) || (skeys[j - 1] != key);
+      last = (j + 1 >= M) || (skeys[j + 1] != key);
+      if (head) { rem = grpRem[key + qmin]; U = grpU[key + qmin]; }   // issued early: independent of the set gather below
+      fetch(j, m, nhv);
+    }
+    // segmented reduction towards the head lane over the part of the name that lies inside this wave:
+    // union of the sets, record count, min/max NH
+    bool stop = (lane == 63) || last;
+    u64 tU = m;
+    u32 tcnt = valid ? 1u : 0u, tmin = nhv, tmax = nhv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u64 oU = __shfl_down(tU, d);
+      const u32 ocnt = __shfl_down(tcnt, d), omin = __shfl_down(tmin, d), omax = __shfl_down(tmax, d);
+      const bool ostop = __shfl_down((int) stop, d) != 0;
+      if (!stop && lane + d < 64) { tU |= oU; tcnt += ocnt; tmin = min(tmin, omin); tmax = max(tmax, omax); stop = ostop; }
+    }
+    // Does the wave's last name continue behind the wave?  Then the whole wave fetches the following records
+    // together (coalesced) and reduces the matching prefix, instead of one lane walking them one by one.
+    const bool spill = __shfl((int) (!last), 63) != 0;   // wave-uniform
+    if (spill) {
+      const u32 skey = __shfl(key, 63);
+      size_t nb = (j | 63) + 1;
+      u64 xU = 0;
+      u32 xcnt = 0, xmin = 0xFFFFFFFFu, xmax = 0;
+      for (;;) {
+        const size_t k = nb + lane;
+        const bool match = k < M && skeys[k] == skey;
+        const u64 mm = __ballot(match);
+        const u32 f = (~mm == 0ull) ? 64u : (u32) (__ffsll((long long) ~mm) - 1);   // length of the matching prefix
+        u64 m2 = 0; u32 n2lo = 0xFFFFFFFFu, n2hi = 0;
+        if (lane < f) { u32 n2; fetch(k, m2, n2); n2lo = n2; n2hi = n2; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          m2 |= __shfl_xor(m2, d); n2lo = min(n2lo, __shfl_xor(n2lo, d)); n2hi = max(n2hi, __shfl_xor(n2hi, d));
+        }
+        xU |= m2; xcnt += f; xmin = min(xmin, n2lo); xmax = max(xmax, n2hi);
+        if (f < 64) break;
+        nb += 64;
+      }
+      if (head && j + tcnt == ((j | 63) + 1)) { tU |= xU; tcnt += xcnt; tmin = min(tmin, xmin); tmax = max(tmax, xmax); }
+    }
+    if (!head) continue;
+    const u32 q = key + qmin;
+    if (rem > 0 && tcnt <= rem) {
+      // all records fall into the pending group of this name (their own NH is irrelevant, mmannot.cpp:1681-1684)
+      U |= tU; rem -= tcnt;
+      if (rem == 0) { close_group(U); U = 0; }
+    } else if (rem == 0 && tmin == tmax && tcnt <= tmin) {
+      // one new group, opened by the first record: remaining = NH-1 (mmannot.cpp:1673), order of the others is irrelevant
+      ++opened; U = tU; rem = tmin - tcnt;
+      if (rem == 0) { close_group(U); U = 0; }
+    } else {
+      // order matters (a group closes inside the run: over-complete names, mixed NH): replay in file order
+      for (size_t r = j; r < j + tcnt; ++r) {
+        u64 m2; u32 n2;
+        fetch(r, m2, n2);
+        if (rem == 0) { rem = n2 - 1; U = m2; ++opened; }              // mmannot.cpp:1672-1677
+        else {                                                          // mmannot.cpp:1678-1701
+          --rem; U |= m2;
+          if (rem == 0) { close_group(U); U = 0; }
         }
       }
     }
@@ -594,14 +796,14 @@ __global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem,
 // sorted by slot, file order kept inside a slot.  One lane per slot replays its adds in order, in IEEE
 // double with correctly rounded division, starting from the sum carried from earlier batches.
 __global__ __launch_bounds__(256) void k_ratio_accum(const u32 *__restrict__ skeys, const u32 *__restrict__ svals,
-                                                     const u32 *__restrict__ Mptr, const u32 *__restrict__ nhp, GlobalTable G) {
-  const u32 M = *Mptr;
+                                                     const u32 *__restrict__ info, GlobalTable G) {
+  const u32 M = info[INFO_M];
   for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
     const u32 slot = skeys[j];
     if (j != 0 && skeys[j - 1] == slot) continue;
     double S = G.sum[slot];
     for (size_t k = j; k < M && skeys[k] == slot; ++k) {
-      const u32 nh = nhp ? nhp[svals[k]] : 1u;
+      const u32 nh = svals[k];                 // the payload of a ratio pair is the record's NH
       S = __dadd_rn(S, __ddiv_rn(1.0, (double) nh));
     }
     G.sum[slot] = S;
@@ -672,7 +874,7 @@ struct mm_index {
   int E = 0;
   int4 *d_iv = nullptr, *d_act = nullptr;
   uint2 *d_bins = nullptr;
-  u32 *d_chrBinBase = nullptr, *d_chrNBins = nullptr, *d_chrIvEnd = nullptr;
+  uint4 *d_chrInfo = nullptr;
   u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
   u64 lineMask[64];
 };
@@ -688,7 +890,7 @@ struct mm_ctx {
   int4 *d_aln = nullptr;
   u32 *d_nh = nullptr;
   u64 *d_hm = nullptr;
-  u32 *d_gkey = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
+  u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr;
   size_t last_n = 0;
   // persistent state
@@ -814,6 +1016,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) act[cur[binBase[c] + b]++] = iv[i];
     }
   }
+  std::vector<uint4> chrInfo(n_chromosomes);
+  for (int c = 0; c < n_chromosomes; ++c) chrInfo[c] = make_uint4(binBase[c], nBins[c], ivEnd[c], 0u);
   auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(d, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
@@ -823,9 +1027,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   if ((e = up((void **) &ix->d_iv, iv.data(), n_iv * sizeof(int4))) != hipSuccess ||
       (e = up((void **) &ix->d_act, act.data(), na * sizeof(int4))) != hipSuccess ||
       (e = up((void **) &ix->d_bins, bins.data(), nbt * sizeof(uint2))) != hipSuccess ||
-      (e = up((void **) &ix->d_chrBinBase, binBase.data(), n_chromosomes * 4)) != hipSuccess ||
-      (e = up((void **) &ix->d_chrNBins, nBins.data(), n_chromosomes * 4)) != hipSuccess ||
-      (e = up((void **) &ix->d_chrIvEnd, ivEnd.data(), n_chromosomes * 4)) != hipSuccess) {
+      (e = up((void **) &ix->d_chrInfo, chrInfo.data(), (size_t) n_chromosomes * sizeof(uint4))) != hipSuccess) {
     mm_index_destroy(ix);
     return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
   }
@@ -836,7 +1038,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
 extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_bins);
-  (void) hipFree(ix->d_chrBinBase); (void) hipFree(ix->d_chrNBins); (void) hipFree(ix->d_chrIvEnd);
+  (void) hipFree(ix->d_chrInfo);
   delete ix;
 }
 
@@ -847,10 +1049,10 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[4]) {
 }
 
 static void ctx_free_batch(mm_ctx *c) {
-  (void) hipFree(c->d_aln); (void) hipFree(c->d_nh); (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey);
+  (void) hipFree(c->d_aln); (void) hipFree(c->d_nh); (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tile);
-  c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr;
+  c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
   c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr; c->d_tile = nullptr;
   c->cap = 0;
 }
@@ -872,7 +1074,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
-  HIPCHK(hipMalloc((void **) &c->d_rowTot, 256 * 4)); HIPCHK(hipMalloc((void **) &c->d_M, 4));
+  HIPCHK(hipMalloc((void **) &c->d_rowTot, 256 * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
   *out = c;
   return mm_reset(c);
 }
@@ -910,7 +1112,7 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
   if (n > c->cap) {
     ctx_free_batch(c);
     const size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
-    HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4));
+    HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_gpay, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4)); HIPCHK(hipMalloc((void **) &c->d_tile, (nblk + 1) * 4));
@@ -943,7 +1145,7 @@ static int ensure_qids(mm_ctx *c, u64 qid_bound) {
 static void fill_params(const mm_ctx *c, ProbeParams &P) {
   const mm_index *ix = c->ix;
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
-  P.chrBinBase = ix->d_chrBinBase; P.chrNBins = ix->d_chrNBins; P.chrIvEnd = ix->d_chrIvEnd;
+  P.chrInfo = ix->d_chrInfo;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
   P.overlapMode = c->opt.overlap_mode; P.overlapValue = c->opt.overlap_value;
@@ -957,19 +1159,20 @@ static int bits_for(u64 bound) {
   return b;
 }
 
-// stable sort of the M (device-side count) pairs in (kA,vA) by the low `bits` bits; result pointers returned
-static int sort_pairs(mm_ctx *c, size_t n_cap, int bits, u32 **sk, u32 **sv) {
+// Stable LSD sort of the batch's pairs (kA,vA) on the low `max_bits` key bits.  The passes the batch's actual key
+// range does not need return immediately (device-side decision, no host round trip); the consumer works out from
+// the same device scalars whether the result sits in A or B.
+static int sort_pairs(mm_ctx *c, size_t n_cap, int max_bits, int fixed_bits) {
   const u32 nblk = (u32) ((n_cap + RS_TILE - 1) / RS_TILE);
   u32 *kin = c->d_kA, *vin = c->d_vA, *kout = c->d_kB, *vout = c->d_vB;
-  for (int shift = 0; shift < bits; shift += 8) {
-    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, c->d_M, shift, c->d_hist, nblk);
-    hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot);
-    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot);
-    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, shift, c->d_hist,
-                       c->d_rowTot, nblk);
+  for (int shift = 0; shift < max_bits; shift += 8) {
+    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, c->d_M, shift, fixed_bits, c->d_hist, nblk);
+    hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, shift, fixed_bits);
+    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, shift, fixed_bits);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, shift, fixed_bits,
+                       c->d_hist, c->d_rowTot, nblk);
     std::swap(kin, kout); std::swap(vin, vout);
   }
-  *sk = kin; *sv = vin;
   HIPCHK(hipGetLastError());
   return MM_OK;
 }
@@ -999,17 +1202,18 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
   u64 *hm = c->d_hm;
   u32 *gkey = need_groups ? c->d_gkey : nullptr;
+  if (need_groups) HIPCHK(hipMemsetAsync(c->d_M, 0, INFO_WORDS * 4, c->stream));
   {
   PhaseTimer t(c, MM_PHASE_PROBE);
   switch (c->opt.overlap_mode) {
     case MM_OVL_INCLUSION:
-      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     case MM_OVL_PC:
-      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     default:
-      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
   }
   }
   HIPCHK(hipGetLastError());
@@ -1020,19 +1224,20 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
       PhaseTimer t(c, MM_PHASE_COMPACT);
       hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, n, c->d_tile);
       hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, c->stream, c->d_tile, nblk, c->d_M);
-      hipLaunchKernelGGL(k_emit_pairs, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, n, c->d_tile, c->d_kA, c->d_vA);
+      hipLaunchKernelGGL(k_emit_pairs, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, c->d_gpay, n, c->d_tile, c->d_M, dflt ? 1 : 0,
+                         c->d_kA, c->d_vA);
     }
-    u32 *sk, *sv;
     {
       PhaseTimer t(c, MM_PHASE_SORT);
-      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, &sk, &sv);
+      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, dflt ? 0 : 16);
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
     if (dflt)
-      hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, sk, sv, c->d_M, d_nh, hm, c->d_grpRem, c->d_grpU, c->G, c->d_stats);
-    else
-      hipLaunchKernelGGL(k_ratio_accum, dim3(grid), dim3(256), 0, c->stream, sk, sv, c->d_M, d_nh, c->G);
+      hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
+                         c->d_grpRem, c->d_grpU, c->G, c->d_stats);
+    else  // 16 key bits = two passes: the sorted pairs are back in A
+      hipLaunchKernelGGL(k_ratio_accum, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_M, c->G);
     HIPCHK(hipGetLastError());
   }
   return MM_OK;
