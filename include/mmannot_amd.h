@@ -105,8 +105,9 @@ int mm_index_create(mm_index **out, const mm_elements *elems, int32_t n_chromoso
                     const int32_t *chr, const int32_t *start, const int32_t *end, const uint8_t *type,
                     const uint8_t *strand, int device, int bin_shift);
 void mm_index_destroy(mm_index *ix);
-/* sizes of the device structures (bytes): [0]=interval records [1]=bin table [2]=active lists, [3]=bin shift */
-int mm_index_info(const mm_index *ix, uint64_t info[4]);
+/* sizes of the device structures (bytes): full index [0]=interval records [1]=bin table [2]=active lists [3]=its bin shift;
+ * compact index [4]=slots (128 B per bin) [5]=flat record lists [6]=its bin shift [7]=0 */
+int mm_index_info(const mm_index *ix, uint64_t info[8]);
 
 /* ---- context: replaces Counter (clear/read/getCounts/dump). stream: hipStream_t or NULL (a private stream). */
 int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options *opt, void *stream);

@@ -83,6 +83,13 @@ struct ProbeParams {
   const int4 *act;         // same record format
   const uint2 *bins;       // per chromosome nbins+1 entries {first, actOff}
   const uint4 *chrInfo;     // per chromosome {first bin record, number of bins, end of its interval range, 0}
+  // compact "slot" index used for every read with end >= start (see slot_walk)
+  const uint4 *slots;       // 128 B per bin: {nAct | nIv<<16, offset into flat, rec0} {rec1, rec2} ... 15 records
+  const uint2 *flat;        // every bin's full record list (only read when a bin holds more than 15 records)
+  const uint2 *chrSlot;     // per chromosome {first slot, number of slots}
+  const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
+  u32 sshift;
+  int useSlots;
   u32 nchr;
   u32 shift;
   u64 elemF, elemR, elemUp, elemDown;  // bit e set: element e is declared '+', '-', is "upstream", is "downstream"
@@ -91,7 +98,7 @@ struct ProbeParams {
   int strandedness;
   int strategy;
   int keep;
-  u64 lineMask[64];        // lineMask[e] = elements on the same Order line as e
+  const u64 *lineMask;     // [64] lineMask[e] = elements on the same Order line as e (device memory: indexed per lane)
 };
 
 __device__ __forceinline__ u32 hash64(u64 k) {
@@ -103,10 +110,13 @@ struct LdsTable {
   u64 key[LT_CAP];
   u32 cnt[LT_CAP];
   u32 slot[LT_CAP];   // cached slot of the set in the global table (NO_KEY = not looked up yet)
+  u32 single[64];     // counts of the single-element sets {e} (by far the most frequent): no hashing
+  u32 singleSlot[64];
 };
 
 __device__ __forceinline__ void lds_table_init(LdsTable &t) {
   for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; t.slot[i] = NO_KEY; }
+  if (threadIdx.x < 64) { t.single[threadIdx.x] = 0; t.singleSlot[threadIdx.x] = NO_KEY; }
 }
 
 __device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
@@ -144,6 +154,22 @@ __device__ __forceinline__ u32 lds_cached_slot(LdsTable &t, const struct GlobalT
   return gt_find_or_insert(g, m);
 }
 
+// per-lane: count one occurrence of set m / get the global slot of set m (no wave-level serialisation)
+__device__ __forceinline__ void gt_add(const struct GlobalTable &g, u64 m, u64 inc);
+__device__ __forceinline__ void count_set(LdsTable &t, const struct GlobalTable &g, u64 m) {
+  if ((m & (m - 1)) == 0) atomicAdd(&t.single[__ffsll((long long) m) - 1], 1u);
+  else if (!lds_table_add(t, m, 1)) gt_add(g, m, 1);
+}
+__device__ __forceinline__ u32 slot_of_set(LdsTable &t, const struct GlobalTable &g, u64 m) {
+  if ((m & (m - 1)) == 0) {
+    const int e = __ffsll((long long) m) - 1;
+    u32 sl = *(volatile u32 *) &t.singleSlot[e];
+    if (sl == NO_KEY) { sl = gt_find_or_insert(g, m); t.singleSlot[e] = sl; }
+    return sl;
+  }
+  return lds_cached_slot(t, g, m);
+}
+
 // returns slot or NO_KEY when full (error flag raised)
 __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
   u32 h = hash64(m) & (GT_CAP - 1);
@@ -166,6 +192,11 @@ __device__ __forceinline__ void gt_add(const GlobalTable &g, u64 m, u64 inc) {
 }
 
 __device__ __forceinline__ void lds_table_flush(LdsTable &t, const GlobalTable &g) {
+  if (threadIdx.x < 64 && t.single[threadIdx.x]) {
+    const u32 sl = t.singleSlot[threadIdx.x];
+    if (sl != NO_KEY) atomicAdd(&g.cnt[sl], (u64) t.single[threadIdx.x]);
+    else gt_add(g, 1ull << threadIdx.x, (u64) t.single[threadIdx.x]);
+  }
   for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) {
     const u64 k = t.key[i];
     const u32 c = t.cnt[i];
@@ -238,7 +269,7 @@ __device__ __forceinline__ bool locate(const ProbeParams &P, u32 tid1, int s, Ca
 // last passing interval of element `t` in index order -> its (overlap, distance): what
 // EvaluationStructure::set leaves in evaluation[t] (mmannot.cpp:1023-1028, 1316-1323)
 template <int OVL>
-__device__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, int rstrand, u32 t, u32 &o_out, u32 &d_out) {
+__device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, int rstrand, u32 t, u32 &o_out, u32 &d_out) {
   const bool up = (P.elemUp >> t) & 1, down = (P.elemDown >> t) & 1;
   for (u32 k = c.a0; k < c.a1; ++k) {
     const int4 r = P.act[k];
@@ -255,6 +286,115 @@ __device__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, 
       o_out = o; d_out = up ? rd_distance(s, e, r.y) : (down ? rd_distance(s, e, r.x) : 0u);
     }
   }
+}
+
+// ---- compact index --------------------------------------------------------------------------------------
+// 8-byte candidate record: x = start; y = len:22 | type:6 | ok('-' read):1 | ok('+' read):1 | long:1 | 0.
+// The two "ok" bits are checkStrand (mmannot.cpp:438-443) evaluated at build time for both read strands.
+// A bin's slot lists, in index order, the intervals open at the bin's left edge followed by the intervals
+// starting inside the bin: exactly act(b) ++ iv[first(b)..] of the 16-byte structure, one cache line.
+#define REC_LEN_BITS 22
+#define REC_LEN_MASK ((1u << REC_LEN_BITS) - 1u)
+#define REC_TYPE(y) (((y) >> REC_LEN_BITS) & 63u)
+#define REC_OKBIT 28
+#define REC_LONG (1u << 30)
+
+template <int OVL>
+__device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, int s, int e, int rstrand, u32 &o, int &ie) {
+  const int is = (int) rx;
+  const u32 len = ry & REC_LEN_MASK;
+  ie = (ry & REC_LONG) ? P.longEnd[len] : is + (int) len;
+  const bool ok = (ry >> (REC_OKBIT + rstrand)) & 1u;
+  if (OVL == MM_OVL_INCLUSION) { o = 1; return ok && is <= s && e <= ie; }
+  const int lo = max(s, is), hi = min(e, ie);
+  if (lo >= hi) return false;
+  const u32 ov = (u32) (hi - lo);
+  o = ov;
+  if (OVL == MM_OVL_PC) {
+    const u32 size = (u32) (e - s + 1);
+    const float lhs = __fmul_rn((float) size, P.overlapValue);
+    return ok && (lhs <= (float) ov);
+  }
+  return ok && ((float) ov >= P.overlapValue);
+}
+
+template <int OVL>
+__device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, int rstrand, u32 t, u32 &o_out, u32 &d_out);
+
+// scan() + getFirst() through the compact index, for a read with e >= s.
+// Pass 1 visits the whole slot of the bin of s, then only the "starts here" part of the following bins up to the bin
+// of e, and collects the set of hit elements.  The slot's first 32 bytes (header + 3 records) are requested first, the
+// rest of its first half and its second half only when the header says they hold records.  The rare pass 2 (several
+// elements of the winning Order line hit) re-walks the full 16-byte structure, which lists the same candidates.
+template <int OVL>
+__device__ __forceinline__ u64 probe_slots(const ProbeParams &P, int s, int e, u32 tid1, int rstrand, u32 &walked) {
+  if (tid1 == 0 || tid1 > P.nchr) return 0;
+  const uint2 cs = P.chrSlot[tid1 - 1];
+  const u32 nb = cs.y;
+  if (nb == 0) return 0;
+  u64 hit = 0;
+#define MM_VISIT(RX, RY)                                                                   \
+  {                                                                                        \
+    u32 o_; int ie_;                                                                       \
+    if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) hit |= 1ull << REC_TYPE(RY); \
+    ++walked;                                                                              \
+  }
+  const u32 b0 = min((u32) s >> P.sshift, nb - 1), b1 = min((u32) e >> P.sshift, nb - 1);
+  for (u32 b = b0; b <= b1; ++b) {
+    const uint4 *S = P.slots + (size_t) (cs.x + b) * 8;
+    const uint4 q0 = S[0], q1 = S[1];
+    const u32 nAct = q0.x & 0xffffu, n = nAct + (q0.x >> 16);
+    const u32 first = (b == b0) ? 0u : nAct;
+    if (first == 0 && n > 0) MM_VISIT(q0.z, q0.w)
+    if (first <= 1 && n > 1) MM_VISIT(q1.x, q1.y)
+    if (first <= 2 && n > 2) MM_VISIT(q1.z, q1.w)
+    if (n > 3) {
+      const uint4 q2 = S[2], q3 = S[3];
+      if (first <= 3) MM_VISIT(q2.x, q2.y)
+      if (first <= 4 && n > 4) MM_VISIT(q2.z, q2.w)
+      if (first <= 5 && n > 5) MM_VISIT(q3.x, q3.y)
+      if (first <= 6 && n > 6) MM_VISIT(q3.z, q3.w)
+      if (n > 7) {
+        const uint4 q4 = S[4], q5 = S[5], q6 = S[6], q7 = S[7];
+        if (first <= 7) MM_VISIT(q4.x, q4.y)
+        if (first <= 8 && n > 8) MM_VISIT(q4.z, q4.w)
+        if (first <= 9 && n > 9) MM_VISIT(q5.x, q5.y)
+        if (first <= 10 && n > 10) MM_VISIT(q5.z, q5.w)
+        if (first <= 11 && n > 11) MM_VISIT(q6.x, q6.y)
+        if (first <= 12 && n > 12) MM_VISIT(q6.z, q6.w)
+        if (first <= 13 && n > 13) MM_VISIT(q7.x, q7.y)
+        if (first <= 14 && n > 14) MM_VISIT(q7.z, q7.w)
+        for (u32 k = max(15u, first); k < n; k += 4) {   // rare long lists: four loads in flight per round trip
+          const uint2 *F = P.flat + q0.y;
+          const uint2 r0 = F[k], r1 = F[min(k + 1, n - 1)], r2 = F[min(k + 2, n - 1)], r3 = F[min(k + 3, n - 1)];
+          MM_VISIT(r0.x, r0.y)
+          if (k + 1 < n) MM_VISIT(r1.x, r1.y)
+          if (k + 2 < n) MM_VISIT(r2.x, r2.y)
+          if (k + 3 < n) MM_VISIT(r3.x, r3.y)
+        }
+      }
+    }
+  }
+#undef MM_VISIT
+  if (!hit) return 0;
+  const int low = __ffsll((long long) hit) - 1;
+  const u64 cand = hit & P.lineMask[low];
+  if ((cand & (cand - 1)) == 0) return cand;
+  Cand c;
+  if (!locate(P, tid1, s, c)) return 0;
+  u64 sel = 0;
+  u32 maxO = 0, minD = 0;
+  for (u64 cm = cand; cm; cm &= cm - 1) {
+    const u32 t = (u32) (__ffsll((long long) cm) - 1);
+    u32 o = 0, d = 0;
+    last_of_type<OVL>(P, c, s, e, rstrand, t, o, d);
+    if (o > maxO) { maxO = o; minD = d; sel = 1ull << t; }
+    else if (o == maxO) {
+      if (d < minD) { minD = d; sel = 1ull << t; }
+      else if (d == minD) sel |= 1ull << t;
+    }
+  }
+  return sel;
 }
 
 // scan() + getFirst() for one read -> element set
@@ -353,7 +493,9 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
     if (processed) {
       const int rec_strand = a.z & 1;
       const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
-      mask = probe_one<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked);
+      // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
+      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked)
+                                        : probe_one<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked);
     }
     const int np = __popcll(mask);
     const bool grouped = processed && grouped_strategy && nh > 1;
@@ -370,29 +512,14 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
       qinv = max(qinv, ~key); qmax = max(qmax, key);
       if (nh >= 0xFFFFu) big = 1;
     }
-    // wave aggregation over equal element sets: one table operation per distinct set and wave.
-    //   per-hit branch (default/unique): the set is counted now (LDS table);
+    // counting / slot lookup, per lane through the workgroup's LDS tables:
+    //   per-hit branch (default/unique): the set is counted now;
     //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
     //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
-    const bool want_slot = (ratio && counted) || (grouped && mask != 0);
-    bool active = counted || want_slot;
-    u64 bal;
-    while ((bal = __ballot(active)) != 0) {
-      const int leader = __ffsll((long long) bal) - 1;
-      const u64 m = __shfl(mask, leader);
-      const bool same = active && (mask == m);
-      const u64 cb = __ballot(same && counted && !ratio);
-      const u64 wb = __ballot(same && want_slot);
-      u32 slot = 0;
-      if ((int) lane == leader) {
-        if (cb) { const u32 c = (u32) __popcll(cb); if (!lds_table_add(T, m, c)) gt_add(G, m, c); }
-        if (wb) slot = lds_cached_slot(T, G, m);
-      }
-      if (wb) {
-        slot = __shfl(slot, leader);
-        if (same && want_slot) { if (ratio) key = slot; else pay = slot & 0xFFFFu; }
-      }
-      active = active && !same;
+    if (counted && !ratio) count_set(T, G, mask);
+    if ((ratio && counted) || (grouped && mask != 0)) {
+      const u32 slot = slot_of_set(T, G, mask);
+      if (ratio) key = slot; else pay = slot & 0xFFFFu;
     }
     if (valid) {
       if (gkey) {
@@ -671,14 +798,14 @@ __global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ k
   const u32 lane = threadIdx.x & 63;
   u32 opened = 0, rescued = 0;
   // record k of the sorted stream -> (element set, NH)
-  auto fetch = [&](size_t k, u64 &m, u32 &nhv) {
+  auto fetch = [&](size_t k, u64 &m, u32 &nhv) __attribute__((always_inline)) {
     const u32 pv = svals[k];
     if (by_index) { m = hm[pv]; nhv = nhp[pv]; }
     else { const u32 slot = pv & 0xFFFFu; m = (slot == 0xFFFFu) ? 0ull : G.key[slot]; nhv = pv >> 16; }
   };
-  auto close_group = [&](u64 U) {
+  auto close_group = [&](u64 U) __attribute__((always_inline)) {
     if (U) {
-      if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
+      count_set(T, G, U);
       if ((U & (U - 1)) == 0) ++rescued;
     }
   };
@@ -780,7 +907,7 @@ __global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem,
     if (grpRem[q] != 0) {
       const u64 U = grpU[q];
       if (U) {
-        if (!lds_table_add(T, U, 1)) gt_add(G, U, 1);
+        count_set(T, G, U);
         if ((U & (U - 1)) == 0) ++rescued;    // rawCounts > 1 always holds for a pending group, mmannot.cpp:1789
       }
       grpRem[q] = 0; grpU[q] = 0;
@@ -875,6 +1002,12 @@ struct mm_index {
   int4 *d_iv = nullptr, *d_act = nullptr;
   uint2 *d_bins = nullptr;
   uint4 *d_chrInfo = nullptr;
+  u64 *d_lineMask = nullptr;
+  uint4 *d_slots = nullptr;
+  uint2 *d_flat = nullptr, *d_chrSlot = nullptr;
+  int *d_longEnd = nullptr;
+  int sshift = 0;
+  size_t n_slots = 0, n_flat = 0;
   u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
   u64 lineMask[64];
 };
@@ -1016,6 +1149,86 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) act[cur[binBase[c] + b]++] = iv[i];
     }
   }
+  // ---- compact slot index (see slot_walk)
+  std::vector<uint2> chrSlot(n_chromosomes, make_uint2(0u, 0u));
+  std::vector<uint4> slots;
+  std::vector<uint2> flat;
+  std::vector<int> longEnd;
+  {
+    // Bin width.  A wave is as slow as its slowest lane, and bins holding more than 15 records leave the one-line
+    // fast path, so the widest bin width is chosen whose share of such bins stays below 0.2 % (64 lanes: most waves
+    // then never see one), among the widths whose table (128 B per bin) fits 256 MB.  Record counts per bin are
+    // heavy-tailed (gene-dense regions), which is why the mean is not the criterion.
+    int best = -1, fallback = -1;
+    for (int sh = 20; sh >= 7; --sh) {
+      u64 nb = 0;
+      std::vector<u64> base(n_chromosomes + 1, 0);
+      for (int c = 0; c < n_chromosomes; ++c) { base[c] = nb; if (seen[c]) nb += (u64) (maxEnd[c] >> sh) + 2; }
+      if (nb * 128ull > (256ull << 20)) break;
+      fallback = sh;
+      std::vector<int32_t> diff(nb + 2, 0), cnt(nb + 1, 0);
+      for (size_t i = 0; i < n_iv; ++i) {
+        if (end[i] < start[i]) continue;
+        const u64 b0 = base[chr[i]] + ((u32) start[i] >> sh), b1 = base[chr[i]] + (((u32) end[i] + 1u) >> sh);
+        ++cnt[b0];
+        if (b1 > b0) { ++diff[b0 + 1]; --diff[b1 + 1]; }
+      }
+      u64 over = 0;
+      int32_t run = 0;
+      for (u64 k = 0; k <= nb; ++k) { run += diff[k]; if (cnt[k] + run > 15) ++over; }
+      if ((double) over <= 0.002 * (double) nb) { best = sh; break; }
+    }
+    if (best < 0) best = fallback < 0 ? 20 : fallback;
+    const int sh = bin_shift > 0 ? std::min(std::max(bin_shift, 7), 20) : best;
+    ix->sshift = sh;
+    std::vector<u32> sBase(n_chromosomes, 0), sN(n_chromosomes, 0);
+    u64 ns = 0;
+    for (int c = 0; c < n_chromosomes; ++c) {
+      if (!seen[c]) continue;
+      sN[c] = (u32) (maxEnd[c] >> sh) + 1; sBase[c] = (u32) ns; ns += sN[c];
+      chrSlot[c] = make_uint2(sBase[c], sN[c]);
+    }
+    std::vector<u32> nAct(ns, 0), nIv(ns, 0);
+    for (size_t i = 0; i < n_iv; ++i) {
+      if (end[i] < start[i]) continue;   // inverted zero-size intervals (e.g. -d 0) can only concern reads without CIGAR operations
+      const int c = chr[i];
+      ++nIv[sBase[c] + ((u32) start[i] >> sh)];
+      const u32 b0 = ((u32) start[i] >> sh) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
+      for (u32 b = b0; b <= b1; ++b) ++nAct[sBase[c] + b];
+    }
+    std::vector<u64> off(ns + 1, 0);
+    for (u64 k = 0; k < ns; ++k) off[k + 1] = off[k] + nAct[k] + nIv[k];
+    if (off[ns] >= 0xFFFFFFF0ull) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: slot lists too large; raise bin_shift"); }
+    flat.resize(off[ns] ? off[ns] : 1);
+    std::vector<u32> curA(ns), curI(ns);
+    for (u64 k = 0; k < ns; ++k) { curA[k] = (u32) off[k]; curI[k] = (u32) off[k] + nAct[k]; }
+    for (size_t i = 0; i < n_iv; ++i) {
+      if (end[i] < start[i]) continue;
+      const int c = chr[i];
+      const u32 t = type[i];
+      const bool ivF = strand[i] == MM_STRAND_F;
+      const bool eF = (ix->elemF >> t) & 1, eR = (ix->elemR >> t) & 1;
+      const bool okPlus = !(eF | eR) || (eF ? ivF : !ivF), okMinus = !(eF | eR) || (eF ? !ivF : ivF);
+      u32 len = (u32) (end[i] - start[i]), y = 0;
+      if (len >= REC_LEN_MASK) { y |= REC_LONG; len = (u32) longEnd.size(); longEnd.push_back(end[i]); }
+      y |= len | (t << REC_LEN_BITS) | ((okMinus ? 1u : 0u) << REC_OKBIT) | ((okPlus ? 1u : 0u) << (REC_OKBIT + 1));
+      const uint2 rec = make_uint2((u32) start[i], y);
+      flat[curI[sBase[c] + ((u32) start[i] >> sh)]++] = rec;
+      const u32 b0 = ((u32) start[i] >> sh) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
+      for (u32 b = b0; b <= b1; ++b) flat[curA[sBase[c] + b]++] = rec;
+    }
+    if (longEnd.size() >= REC_LEN_MASK) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: too many very long intervals"); }
+    slots.assign(ns * 8, make_uint4(0u, 0u, 0u, 0u));
+    for (u64 k = 0; k < ns; ++k) {
+      u32 *w = (u32 *) &slots[k * 8];
+      w[0] = nAct[k] | (nIv[k] << 16);
+      w[1] = (u32) off[k];
+      if (nAct[k] > 0xFFFFu || nIv[k] > 0xFFFFu) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: more than 65535 intervals in one bin; lower bin_shift"); }
+      const u32 n = std::min<u32>(nAct[k] + nIv[k], 15u);
+      for (u32 r = 0; r < n; ++r) { w[2 + 2 * r] = flat[off[k] + r].x; w[3 + 2 * r] = flat[off[k] + r].y; }
+    }
+    ix->n_slots = ns; ix->n_flat = off[ns];
+  }
   std::vector<uint4> chrInfo(n_chromosomes);
   for (int c = 0; c < n_chromosomes; ++c) chrInfo[c] = make_uint4(binBase[c], nBins[c], ivEnd[c], 0u);
   auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
@@ -1027,7 +1240,12 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   if ((e = up((void **) &ix->d_iv, iv.data(), n_iv * sizeof(int4))) != hipSuccess ||
       (e = up((void **) &ix->d_act, act.data(), na * sizeof(int4))) != hipSuccess ||
       (e = up((void **) &ix->d_bins, bins.data(), nbt * sizeof(uint2))) != hipSuccess ||
-      (e = up((void **) &ix->d_chrInfo, chrInfo.data(), (size_t) n_chromosomes * sizeof(uint4))) != hipSuccess) {
+      (e = up((void **) &ix->d_chrInfo, chrInfo.data(), (size_t) n_chromosomes * sizeof(uint4))) != hipSuccess ||
+      (e = up((void **) &ix->d_lineMask, ix->lineMask, 64 * sizeof(u64))) != hipSuccess ||
+      (e = up((void **) &ix->d_slots, slots.data(), slots.size() * sizeof(uint4))) != hipSuccess ||
+      (e = up((void **) &ix->d_flat, flat.data(), flat.size() * sizeof(uint2))) != hipSuccess ||
+      (e = up((void **) &ix->d_chrSlot, chrSlot.data(), (size_t) n_chromosomes * sizeof(uint2))) != hipSuccess ||
+      (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess) {
     mm_index_destroy(ix);
     return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
   }
@@ -1038,13 +1256,14 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
 extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_bins);
-  (void) hipFree(ix->d_chrInfo);
+  (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
   delete ix;
 }
 
-extern "C" int mm_index_info(const mm_index *ix, uint64_t info[4]) {
+extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
   if (!ix || !info) return fail(MM_ERR_ARG, "mm_index_info: null argument");
   info[0] = ix->n_iv * sizeof(int4); info[1] = ix->n_bins * sizeof(uint2); info[2] = ix->n_act * sizeof(int4); info[3] = (u64) ix->shift;
+  info[4] = ix->n_slots * 128ull; info[5] = ix->n_flat * sizeof(uint2); info[6] = (u64) ix->sshift; info[7] = 0;
   return MM_OK;
 }
 
@@ -1146,11 +1365,13 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   const mm_index *ix = c->ix;
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
+  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift;
+  P.useSlots = getenv("MMANNOT_AMD_FULL_INDEX_ONLY") ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
   P.overlapMode = c->opt.overlap_mode; P.overlapValue = c->opt.overlap_value;
   P.strandedness = c->opt.strandedness; P.strategy = c->opt.strategy; P.keep = c->opt.keep_hit_masks;
-  memcpy(P.lineMask, ix->lineMask, sizeof(P.lineMask));
+  P.lineMask = ix->d_lineMask;
 }
 
 static int bits_for(u64 bound) {

@@ -9,7 +9,7 @@ for wl in ("c2", "c3"):
     else:
         an = synth.synth_annotation("tair10", seed=3, scale=1.0); read_len, nh_max = 50, 1
     cfg = mm.Config.from_json(an.config)
-    for shift in (0, 12, 13):
+    for shift in ((0, 11, 13) if wl == "c3" else (0, 8, 10)):
         index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, bin_shift=shift)
         B = 1 << 24
         dev = torch.device("cuda")
