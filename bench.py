@@ -62,11 +62,11 @@ def main():
 
     # ---------------- annotation (same on every rank) -> device index
     if args.workload == "c3":
-        an = synth.synth_annotation("hs38", seed=args.seed, scale=1.5)
+        an = synth.synth_annotation("hs38", seed=args.seed, scale=1.5, keep_genes=(rank == 0 and world == 1))
         read_len, nh_max, scatter = 100, 20, 16
         wname = "c3: synthetic 100bp SE reads, NH=1..20 groups, HS38-scale annotation, -y default -s F -l -1"
     else:
-        an = synth.synth_annotation("tair10", seed=args.seed, scale=1.0)
+        an = synth.synth_annotation("tair10", seed=args.seed, scale=1.0, keep_genes=(rank == 0 and world == 1))
         read_len, nh_max, scatter = 50, 1, 0
         wname = "c2: synthetic 50bp SE reads, NH=1, TAIR10-scale annotation, -y default -s F -l -1"
     cfg = mm.Config.from_json(an.config)
@@ -150,7 +150,13 @@ def main():
             "stats": stats, "table_rows": int(len(masks)),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, an, read_len, nh_max, scatter, chr_len)
+            port = cpu_baseline(args, an, read_len, nh_max, scatter, chr_len)
+            ref = cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, cfg)
+            if ref is not None:
+                ref["port_single_thread"] = {k: port[k] for k in ("value", "sample")}
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = port
         print(json.dumps(out))
     ctr.close(); index.close()
     if world > 1:
@@ -171,6 +177,68 @@ def cpu_baseline(args, an, read_len, nh_max, scatter, chr_len):
     return {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
             "sample": f"first 2^{args.cpu_sample_log2} alignments of rank 0's stream, oracle/mm_oracle.c single thread, {dt:.1f} s",
             "stats": r.stats}
+
+
+def cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, cfg):
+    """The reference itself (oracle/_ref/mmannot_patched = v1.1 + the one-line strand fix that makes -s F deterministic,
+    SURVEY.md F1), compiled in the build container, on a bounded sample of the same workload: the synthetic GTF and
+    configuration as files, S BAM shards of 2^21 alignments of rank 0's stream, `-t S` (the reference parallelises over
+    input files only).  The GTF-loading time (measured by a run on a one-read BAM) is subtracted.  Shard 0 is also run
+    alone and its count table must equal what the GPU path gives for the same tuples."""
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "mmannot_patched")
+    if not os.path.exists(ref) or an.genes is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_ref as sr
+    import mmannot_amd as mm
+    from mmannot_amd import synth
+    from oracle import mm_oracle as mo
+    S = max(1, min(16, os.cpu_count() or 1))
+    n = 1 << 21
+    d = tempfile.mkdtemp(prefix="mmbench")
+    gtf = os.path.join(d, "a.gtf"); open(gtf, "w").write(synth.gtf_text(an))
+    cfgp = os.path.join(d, "c.cfg"); open(cfgp, "w").write(synth.config_text(an.shape))
+    chroms = [(c, int(l)) for c, l in zip(an.chr_names, an.chr_len)]
+    shards, first_tuples = [], None
+    for i in range(S):
+        t = sr.synth_tuples(args.seed * 1000003, i * n, n, read_len, nh_max, chr_len, scatter)
+        if i == 0:
+            first_tuples = t
+        body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"],
+                                    np.full(n, read_len), t["nh"] if nh_max > 1 else None)
+        p = os.path.join(d, f"s{i}.bam"); mo.write_bam_bytes(p, chroms, body, level=1); shards.append(p)
+    one = os.path.join(d, "one.bam")
+    mo.write_bam_bytes(one, chroms, mo.bam_records_fixed(np.array([0]), np.array([100]), np.array([0], dtype=np.uint16), np.array([0]), np.array([read_len]), None), level=1)
+
+    def run(files, threads, out):
+        t0 = time.perf_counter()
+        p = subprocess.run([ref, "-a", gtf, "-c", cfgp, "-s", "F", "-t", str(threads), "-o", out, "-r"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        return time.perf_counter() - t0
+    t_fixed = run([one], 1, os.path.join(d, "t0.tsv"))
+    t_one = run([shards[0]], 1, os.path.join(d, "t1.tsv"))
+    t_full = run(shards, S, os.path.join(d, "tS.tsv"))
+    # bench-time parity: GPU path on shard 0's tuples == the reference's table for shard 0
+    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy="default")
+    t = first_tuples
+    # the reference resolves chromosomes by name: reads on a chromosome without intervals are 'unknown' to it
+    has_iv = np.zeros(an.n_chromosomes + 1, dtype=bool); has_iv[np.unique(an.chr)] = True
+    tid = np.where(has_iv[t["tid"]], t["tid"], -1)
+    ctr.add_batch(mm.pack_alignments(tid, t["start"], t["end"], t["strand"], t["qid"]), t["nh"], int(t["qid"].max()) + 1)
+    ctr.flush()
+    tab = mm.TableCount(cfg, 1); tab.addCounter(ctr)
+    parity = tab.dump(["s0"]) == open(os.path.join(d, "t1.tsv")).read()
+    ctr.close()
+    assert parity, "GPU table differs from the compiled reference on shard 0"
+    rate = S * n / max(1e-9, t_full - t_fixed)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return {"value": rate, "unit": "alignments/s", "cores": S, "kind": "reference",
+            "sample": f"{S} BAM shards x 2^21 alignments of rank 0's stream, oracle/_ref/mmannot_patched -t {S}: {t_full:.1f} s total, "
+                      f"{t_fixed:.1f} s of it GTF/config loading (subtracted); one shard alone, 1 thread: {n / max(1e-9, t_one - t_fixed):.3g} alignments/s",
+            "parity_table_vs_reference": bool(parity)}
 
 
 if __name__ == "__main__":

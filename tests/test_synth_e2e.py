@@ -1,0 +1,53 @@
+"""End-to-end on seeded synthetic GTF + BAM: the `mmannot-amd` binary (GPU) and the host code + CPU oracle (CPU) against
+the compiled reference's table and stderr (tests/golden/synth_e2e, oracle/gen_synth_golden.py)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+CASES = json.load(open(os.path.join(gu.GOLD, "synth_e2e", "cases.json")))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "mmannot_amd", "mmannot-amd")
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    from oracle import gen_synth_golden as g
+    out = {}
+    for name, c in CASES.items():
+        d = str(tmp_path_factory.mktemp("synth_" + name))
+        out[name] = (d,) + g.make_inputs(c["workload"], d)
+    return out
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_host_plus_oracle(oracle, inputs, name):
+    import mmannot_amd.api as api
+    d, gtf, cfg, bam = inputs[name]
+    for c in CASES[name]["cases"]:
+        o = gu.parse_args(c["args"])
+        an = api.Annotation(cfg, gtf, o["d"], o["D"])
+        dec = api.ReadsDecoder(bam, an, unique_only=(o["strategy"] == "unique"))
+        aln, nh = dec.read_all()
+        desc = oracle.ConfigDesc([oracle.Element(e.source, e.type, e.strand, e.line) for e in an.config().elements])
+        ix = dict(chr=an.chr, start=an.start, end=an.end, type=an.type, strand=an.strand, n_chromosomes=len(an.chromosomes))
+        rd = dict(tid=(aln["tid_strand"] >> 1).astype(np.int64) - 1, start=aln["start"], end=aln["end"], strand=aln["tid_strand"] & 1, nh=nh, qid=aln["qid"])
+        r = oracle.run(desc, ix, rd, overlap=o["overlap"], strandedness=o["strandedness"], strategy=o["strategy"])
+        assert oracle.format_table(desc, r.row_mask, r.row_count, "r") == c["table"], c["args"]
+        assert oracle.format_stats(r.stats, "$D/r.bam") in c["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_cli(gpu_lib, inputs, name):
+    d, gtf, cfg, bam = inputs[name]
+    for c in CASES[name]["cases"]:
+        out = os.path.join(d, "t.tsv")
+        p = subprocess.run([CLI, "-a", gtf, "-r", bam, "-c", cfg, "-o", out] + c["args"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == c["rc"], p.stderr.decode()
+        assert open(out).read() == c["table"], c["args"]
+        assert p.stderr.decode().replace(d, "$D") == c["stderr"], c["args"]
