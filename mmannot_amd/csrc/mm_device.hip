@@ -51,6 +51,7 @@ extern "C" const char *mm_version(void) { return MM_VERSION; }
 #define LT_CAP 1024u               // per-workgroup LDS table
 #define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
+#define MM_LDS_CHR 512               // chromosome tables up to this size are staged in LDS by k_probe
 
 // per-batch scalars kept on the device (no host round trip between the kernels of one batch)
 enum { INFO_M = 0,      // number of records in the grouping pipeline
@@ -327,9 +328,10 @@ __device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c
 // rest of its first half and its second half only when the header says they hold records.  The rare pass 2 (several
 // elements of the winning Order line hit) re-walks the full 16-byte structure, which lists the same candidates.
 template <int OVL>
-__device__ __forceinline__ u64 probe_slots(const ProbeParams &P, int s, int e, u32 tid1, int rstrand, u32 &walked) {
+__device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *chrSlot, const u64 *lineMask, int s, int e, u32 tid1, int rstrand,
+                                            u32 &walked) {
   if (tid1 == 0 || tid1 > P.nchr) return 0;
-  const uint2 cs = P.chrSlot[tid1 - 1];
+  const uint2 cs = chrSlot[tid1 - 1];
   const u32 nb = cs.y;
   if (nb == 0) return 0;
   u64 hit = 0;
@@ -378,7 +380,7 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, int s, int e, u
 #undef MM_VISIT
   if (!hit) return 0;
   const int low = __ffsll((long long) hit) - 1;
-  const u64 cand = hit & P.lineMask[low];
+  const u64 cand = hit & lineMask[low];
   if ((cand & (cand - 1)) == 0) return cand;
   Cand c;
   if (!locate(P, tid1, s, c)) return 0;
@@ -469,6 +471,11 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
   __shared__ LdsTable T;
   __shared__ u32 sstat[8];
   __shared__ u32 sq[3];   // max(~qid) = ~min, max(qid), saw NH >= 0xFFFF
+  __shared__ u64 sLine[64];          // lineMask and the per-chromosome slot table are read once per alignment:
+  __shared__ uint2 sChr[MM_LDS_CHR]; // keep them in LDS instead of gathering them from global memory
+  if (threadIdx.x < 64) sLine[threadIdx.x] = P.lineMask[threadIdx.x];
+  for (u32 c = threadIdx.x; c < min(P.nchr, (u32) MM_LDS_CHR); c += blockDim.x) sChr[c] = P.chrSlot[c];
+  const uint2 *chrSlot = (P.nchr <= (u32) MM_LDS_CHR) ? sChr : P.chrSlot;
   lds_table_init(T);
   if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
   if (threadIdx.x < 3) sq[threadIdx.x] = 0;
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
       const int rec_strand = a.z & 1;
       const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
       // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
-      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked)
+      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, (u32) a.z >> 1, rstrand, walked)
                                         : probe_one<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked);
     }
     const int np = __popcll(mask);
