@@ -926,21 +926,132 @@ __global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem,
   lds_table_flush(T, G);
 }
 
-// -y ratio: regionCounts[set] += 1.0/nHits in file order (mmannot.cpp:1730).  Input: (slot, index) pairs
-// sorted by slot, file order kept inside a slot.  One lane per slot replays its adds in order, in IEEE
-// double with correctly rounded division, starting from the sum carried from earlier batches.
-__global__ __launch_bounds__(256) void k_ratio_accum(const u32 *__restrict__ skeys, const u32 *__restrict__ svals,
-                                                     const u32 *__restrict__ info, GlobalTable G) {
+// -y ratio: regionCounts[set] += 1.0/nHits, as double, in file order (mmannot.cpp:1730); the table prints
+// round(sum) (mmannot.cpp:1868).  Half-integer sums are common, so the accumulation has to be bit-faithful to the
+// reference's order of additions - yet a hot row receives millions of terms per batch.  Exact parallel form:
+// while the running sum S stays inside one binade [2^k, 2^(k+1)), S = N * u with u = 2^(k-52) and an integer N in
+// [2^52, 2^53); adding x = fl(1/nh) gives fl(S + x) = (N + inc) * u with
+//      inc = round-to-nearest(x / u)        (an integer that does not depend on N)
+// unless x / u lies exactly half-way between two integers (then round-half-even looks at N's parity), which for a
+// given x can happen in exactly one binade: the one where u/2 is x's lowest set bit.  So a chunk of terms is reduced
+// with integer adds (increments of small NH values come from an LDS table rebuilt when the binade changes); a chunk
+// that contains a tie-capable term, an infinite term (NH = 0) or that would leave the binade (the crossing add rounds
+// on the coarser grid) is replayed by one lane with real IEEE adds.  Input: (slot, NH) pairs sorted by slot, file
+// order kept inside a slot; segLo/segHi give each slot's run.
+#define RATIO_SENTINEL 0xFFFFFFFFFFFFFFFFull
+#define RATIO_LUT 4096
+#define RATIO_THREADS 1024
+#define RATIO_PER_THREAD 16
+#define RATIO_SERIAL_STEP 1024      // a chunk that cannot be reduced is replayed this many terms at a time
+#define RATIO_CHUNK (RATIO_THREADS * RATIO_PER_THREAD)
+
+__global__ __launch_bounds__(256) void k_seg_bounds(const u32 *__restrict__ skeys, const u32 *__restrict__ info, u32 *__restrict__ segLo,
+                                                    u32 *__restrict__ segHi) {
   const u32 M = info[INFO_M];
   for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
-    const u32 slot = skeys[j];
-    if (j != 0 && skeys[j - 1] == slot) continue;
-    double S = G.sum[slot];
-    for (size_t k = j; k < M && skeys[k] == slot; ++k) {
-      const u32 nh = svals[k];                 // the payload of a ratio pair is the record's NH
-      S = __dadd_rn(S, __ddiv_rn(1.0, (double) nh));
+    const u32 k = skeys[j];
+    if (j == 0 || skeys[j - 1] != k) segLo[k] = (u32) j;
+    if (j + 1 == M || skeys[j + 1] != k) segHi[k] = (u32) j + 1;
+  }
+}
+
+// increment of N when fl(1/nh) is added to a sum in binade k; RATIO_SENTINEL = "take the serial path"
+__device__ __forceinline__ u64 ratio_inc(u32 nh, int k) {
+  if (nh == 0) return RATIO_SENTINEL;                       // 1.0/0 = inf
+  const double x = __ddiv_rn(1.0, (double) nh);
+  const u64 bx = (u64) __double_as_longlong(x);
+  const u64 Mx = (bx & 0xFFFFFFFFFFFFFull) | (1ull << 52);  // x = Mx * 2^ex (x is normal: nh < 2^32)
+  const int ex = (int) ((bx >> 52) & 0x7FF) - 1075;
+  const int sh = (k - 52) - ex;                             // x / u = Mx / 2^sh
+  if (sh <= 0) return RATIO_SENTINEL;                       // x >= 2^52 u: N + x/u >= 2^53, the add leaves the binade
+  if (sh > 54) return 0;                                    // below u/2: absorbed
+  const u64 q = Mx >> sh;
+  const u64 rem = Mx & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+  if (rem == half) return RATIO_SENTINEL;                   // exact tie: round-half-even depends on N
+  return q + (rem > half ? 1ull : 0ull);
+}
+
+__global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restrict__ svals, const u32 *__restrict__ segLo,
+                                                              const u32 *__restrict__ segHi, GlobalTable G) {
+  __shared__ u64 lut[RATIO_LUT];
+  __shared__ u64 wsum[RATIO_THREADS / 64];
+  __shared__ u32 wflag[RATIO_THREADS / 64];
+  __shared__ double sS;
+  __shared__ int sK, sSerial;
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int kLut = 0x7fffffff;
+  for (u32 slot = blockIdx.x; slot < GT_CAP; slot += gridDim.x) {
+    const u32 lo = segLo[slot], hi = segHi[slot];
+    if (hi <= lo) continue;                                  // block-uniform
+    if (t == 0) sS = G.sum[slot];
+    __syncthreads();
+    for (u32 cb = lo; cb < hi;) {
+      u32 cn = min((u32) RATIO_CHUNK, hi - cb);
+      if (t == 0) {
+        const double S = sS;
+        const u64 bs = (u64) __double_as_longlong(S);
+        const int E = (int) ((bs >> 52) & 0x7FF);
+        sSerial = (E == 0 || E == 0x7FF || S < 0.0) ? 1 : 0;   // zero / subnormal / inf / nan: no binade to work in
+        sK = E - 1023;
+      }
+      __syncthreads();
+      bool serial = sSerial != 0;
+      const int k = sK;
+      if (!serial && k != kLut) {                              // block-uniform: rebuild the increment table for this binade
+        for (u32 v = t; v < RATIO_LUT; v += RATIO_THREADS) lut[v] = ratio_inc(v, k);
+        kLut = k;
+        __syncthreads();
+      }
+      u64 acc = 0;
+      u32 bad = 0;
+      if (!serial) {
+        u32 nhv[RATIO_PER_THREAD];
+#pragma unroll
+        for (int r = 0; r < RATIO_PER_THREAD; ++r) {             // all loads of the chunk are in flight together
+          const u32 i = (u32) r * RATIO_THREADS + t;
+          nhv[r] = (i < cn) ? svals[cb + i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int r = 0; r < RATIO_PER_THREAD; ++r) {
+          const u32 i = (u32) r * RATIO_THREADS + t;
+          if (i < cn) {
+            const u32 nh = nhv[r];
+            const u64 inc = (nh < RATIO_LUT) ? lut[nh] : ratio_inc(nh, k);
+            if (inc == RATIO_SENTINEL) bad = 1; else acc += inc;   // inc < 2^52: 64 lanes x 16 terms stay below 2^63
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off); bad |= __shfl_down(bad, off); }
+        if (lane == 0) { wsum[w] = acc; wflag[w] = bad; }
+        __syncthreads();
+        if (t == 0) {
+          u64 tot = 0; u32 anybad = 0;
+          for (u32 q = 0; q < RATIO_THREADS / 64; ++q) {          // overflow-safe: a wave sum >= 2^53 already means "leaves the binade"
+            if (wsum[q] >= (1ull << 53)) anybad = 1; else tot += wsum[q];
+            anybad |= wflag[q];
+          }
+          const u64 N = ((u64) __double_as_longlong(sS) & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+          if (anybad || tot >= (1ull << 53) || N + tot >= (1ull << 53)) sSerial = 1;   // would leave the binade (or needs N's parity)
+          else {
+            const u64 N2 = N + tot;                             // still in [2^52, 2^53): same exponent, new mantissa
+            sS = __longlong_as_double((long long) ((((u64) (sK + 1023)) << 52) | (N2 & 0xFFFFFFFFFFFFFull)));
+          }
+        }
+        __syncthreads();
+        serial = sSerial != 0;
+      }
+      if (serial) {
+        cn = min(cn, (u32) RATIO_SERIAL_STEP);
+        if (t == 0) {                                           // the reference's own loop, one add at a time
+          double S = sS;
+          for (u32 i = 0; i < cn; ++i) S = __dadd_rn(S, __ddiv_rn(1.0, (double) svals[cb + i]));
+          sS = S;
+        }
+      }
+      cb += cn;
+      __syncthreads();
     }
-    G.sum[slot] = S;
+    if (t == 0) G.sum[slot] = sS;
+    __syncthreads();
   }
 }
 
@@ -1031,7 +1142,7 @@ struct mm_ctx {
   u32 *d_nh = nullptr;
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
-  u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr;
+  u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
   size_t last_n = 0;
   // persistent state
   GlobalTable G{};
@@ -1301,6 +1412,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
   HIPCHK(hipMalloc((void **) &c->d_rowTot, 256 * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
+  HIPCHK(hipMalloc((void **) &c->d_seg, 2 * GT_CAP * 4));
   *out = c;
   return mm_reset(c);
 }
@@ -1311,7 +1423,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
   ctx_free_batch(c);
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
-  (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M);
+  (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
   if (c->own_stream) (void) hipStreamDestroy(c->stream);
   delete c;
@@ -1464,8 +1576,11 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     if (dflt)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
                          c->d_grpRem, c->d_grpU, c->G, c->d_stats);
-    else  // 16 key bits = two passes: the sorted pairs are back in A
-      hipLaunchKernelGGL(k_ratio_accum, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_M, c->G);
+    else {  // 16 key bits = two passes: the sorted pairs are back in A
+      HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
+      hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_M, c->d_seg, c->d_seg + GT_CAP);
+      hipLaunchKernelGGL(k_ratio_rows, dim3(512), dim3(RATIO_THREADS), 0, c->stream, c->d_vA, c->d_seg, c->d_seg + GT_CAP, c->G);
+    }
     HIPCHK(hipGetLastError());
   }
   return MM_OK;

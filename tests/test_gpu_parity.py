@@ -138,3 +138,37 @@ def test_synth_generator_twin(gpu_lib):
         assert ((a[:, 2] >> 1).astype(np.int64) - 1 == t["tid"]).all() and ((a[:, 2] & 1) == t["strand"]).all()
         assert (a[:, 3].astype(np.int64) == t["qid"]).all()
         assert (nh.cpu().numpy().view(np.uint32) == t["nh"]).all()
+
+
+@pytest.mark.parametrize("nh_max,strand,l", [(100, "F", -1.0), (3, "U", 0.5), (1, "R", -1.0)])
+def test_ratio_large_stream(gpu_lib, oracle, nh_max, strand, l):
+    """-y ratio at a size where rows receive 10^5..10^6 terms: the parallel binade-integer accumulation (k_ratio_rows) must
+    reproduce the reference's sequential double sums bit for bit, across batches of uneven sizes."""
+    from mmannot_amd import synth
+    mm = gpu_lib
+    an = synth.synth_annotation("hs38", seed=9, scale=0.05)
+    n = 3_000_000
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, len(an.start), n)                 # reads placed on / next to annotated intervals: ~half of them count
+    st = np.maximum(1, an.start[pick] + rng.integers(-60, 80, n))
+    t = dict(tid=an.chr[pick].astype(np.int32), start=st.astype(np.int64), end=(st + 99).astype(np.int64),
+             strand=rng.integers(0, 2, n).astype(np.uint8), nh=rng.integers(1, nh_max + 1, n).astype(np.uint32),
+             qid=np.arange(n, dtype=np.int64))
+    desc = oracle.ConfigDesc.from_json(an.config)
+    ix = an.as_index_dict()
+    ref = oracle.run(desc, ix, t, overlap=l, strandedness=strand, strategy="ratio")
+    cfg = mm.Config.from_json(an.config)
+    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes)
+    ctr = mm.Counter(index, overlap=l, strandedness=strand, strategy="ratio")
+    aln = mm.pack_alignments(t["tid"], t["start"], t["end"], t["strand"], t["qid"])
+    for a, b in ((0, 1_000_003), (1_000_003, 1_000_004), (1_000_004, 2_500_000), (2_500_000, n)):
+        ctr.add_batch(aln[a:b], t["nh"][a:b], int(t["qid"].max()) + 1)
+        ctr.sync()
+    ctr.flush()
+    masks, sums = ctr.getCounts()
+    assert ctr.stats() == ref.stats
+    got = dict(zip(masks.tolist(), sums.view(np.uint64).tolist()))
+    want = dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
+    assert got == want
+    assert max(ref.row_sum) > (1e4 if nh_max > 3 else 1e5)   # rows large enough to leave the serial warm-up
+    ctr.close(); index.close()
