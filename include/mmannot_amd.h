@@ -136,6 +136,11 @@ int mm_get_rows(mm_ctx *ctx, uint64_t *masks, double *sums, size_t cap, size_t *
 /* Parity/debug: region set of every tuple of the last batch (requires keep_hit_masks);
  * ~0 marks a tuple skipped by -y unique (mmannot.cpp:1773). */
 int mm_get_hit_masks(mm_ctx *ctx, uint64_t *out, size_t n);
+/* -M support, EvaluationStructure::getIds (mmannot.cpp:1077-1081): for every tuple of the last batch, the indices (in the
+ * sorted interval vector given to mm_index_create) of the intervals that passed scan() for the elements of its final set.
+ * counts[n] always; idx (capacity cap) may be NULL to learn *total first.  Requires keep_hit_masks; the batch's tuples must
+ * still be valid (device batches: not yet overwritten by the caller). */
+int mm_get_hit_intervals(mm_ctx *ctx, uint32_t *counts, uint32_t *idx, size_t cap, size_t *total);
 /* Average number of candidate records visited per alignment in the last batch (profiling aid; requires keep_hit_masks). */
 int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
 

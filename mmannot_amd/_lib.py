@@ -63,6 +63,7 @@ SYMBOLS = {
     "mm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mm_get_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mm_get_hit_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mm_get_hit_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

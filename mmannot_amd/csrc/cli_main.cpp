@@ -65,9 +65,34 @@ static std::string stat_line(uint64_t n, const char *label, uint64_t total) {
   return std::string("\t") + label + num + " (" + pc + "%)\n";
 }
 
-struct PendingRead {  // readCounts + rawCounts entry, mmannot.cpp:1656-1657
+// glibc's rand() for an unseeded process (= srand(1)): the TYPE_3 additive feedback generator r[i] = r[i-31] + r[i-3]
+// seeded by the minimal-standard LCG, first 310 outputs discarded, result >> 1.  Replayed here explicitly so that
+// -y random (mmannot.cpp:1711) does not depend on who else in the process calls rand().
+struct GlibcRand {
+  uint32_t r[34];
+  int k = 0;
+  std::vector<uint32_t> st;
+  GlibcRand() {
+    st.resize(344);
+    int64_t x = 1;
+    st[0] = 1;
+    for (int i = 1; i < 31; ++i) { x = (16807 * x) % 2147483647; if (x < 0) x += 2147483647; st[i] = (uint32_t) x; }
+    for (int i = 31; i < 34; ++i) st[i] = st[i - 31];
+    for (int i = 34; i < 344; ++i) st[i] = st[i - 31] + st[i - 3];
+  }
+  uint32_t next() {
+    const size_t n = st.size();
+    const uint32_t v = st[n - 31] + st[n - 3];
+    st.push_back(v);
+    if (st.size() > 4096) st.erase(st.begin(), st.begin() + 2048);
+    return v >> 1;
+  }
+};
+
+struct PendingRead {  // readCounts + rawCounts + readsIntervals entry, mmannot.cpp:1656-1660
   uint32_t remaining, raw;
   std::vector<uint8_t> regions;
+  std::vector<uint32_t> intervals;
 };
 
 int main(int argc, char **argv) {
@@ -141,6 +166,7 @@ int main(int argc, char **argv) {
     else if (s == "-v") { std::cerr << "mmannot v" << VERSION << std::endl; return EXIT_SUCCESS; }
     else if (s == "-h") { usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_SUCCESS; }
     // extensions (not in the reference): device selection and the verbatim-strand compatibility switch
+    else if (s == "--selftest-rand") { GlibcRand g; const int n = std::stoi(next()); for (int k = 0; k < n; ++k) std::cout << g.next() << "\n"; return EXIT_SUCCESS; }
     else if (s == "--device") device = std::stoi(next());
     else if (s == "--compat-strand") {
       s = next();
@@ -177,15 +203,14 @@ int main(int argc, char **argv) {
     usage(overlap, upstream, downstream, rescue_threshold, n_threads);
     return EXIT_FAILURE;
   }
-  if (interval_stats) { std::cerr << "mmannot-amd: -M (per-interval statistics) is not implemented yet.\nExiting." << std::endl; return EXIT_FAILURE; }
-  if (strategy == MM_STRAT_RANDOM) {
-    std::cerr << "mmannot-amd: -y random replays libc rand() in file order and is not a device strategy.\nExiting." << std::endl;
-    return EXIT_FAILURE;
-  }
-  std::ofstream of, read_stats_out;
+  // -m, -M and -y random are the reference's sequential side channels (per-read multisets, per-read interval lists, libc
+  // rand() in file order): the device delivers the per-hit element sets / interval lists, the bookkeeping happens here.
+  const bool host_book = read_stats || interval_stats || strategy == MM_STRAT_RANDOM;
+  std::ofstream of, read_stats_out, interval_stats_out;
   if (!output.empty()) of.open(output.c_str());
   std::ostream &out = output.empty() ? std::cout : of;
   if (read_stats) read_stats_out.open(read_stats_file.c_str());
+  if (interval_stats) interval_stats_out.open(interval_stats_file.c_str());
 
   mm_annotation *an = nullptr;
   if (mm_annotation_load(&an, config.c_str(), gtf.c_str(), upstream, downstream) != MM_OK) {
@@ -197,7 +222,7 @@ int main(int argc, char **argv) {
   if (mm_index_from_annotation(&index, an, device, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
   mm_options opt;
   opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
-  opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = read_stats ? 1 : 0;
+  opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0;
   mm_ctx *ctx = nullptr;
   if (mm_ctx_create(&ctx, index, &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
   const int32_t E = mm_annotation_n_elements(an);
@@ -214,11 +239,16 @@ int main(int argc, char **argv) {
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
     if (rc != MM_OK) { std::cerr << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
-    // -m bookkeeping (host): the multiset of element ids per pending read
+    // host bookkeeping for -m / -M / -y random
     std::unordered_map<uint32_t, PendingRead> pending;
     std::map<uint64_t, double> host_counts;
+    std::map<std::vector<uint32_t>, unsigned> interval_counts;      // intervalCounts, mmannot.cpp:1659
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> rnd_choice;   // chosenId / numberSeen, mmannot.cpp:1661
+    std::vector<bool> rnd_seen;                                      // seen, mmannot.cpp:1662
+    GlibcRand grand;
     uint64_t h_reads = 0, h_rescued = 0;
     auto print_read_stats = [&](uint32_t qid, unsigned nhits, std::vector<uint8_t> &regions) -> void {  // :474-493 + rescue :497-509
+      if (!read_stats) return;
       std::sort(regions.begin(), regions.end());
       read_stats_out << mm_reader_name(rd, qid) << " \t" << nhits;
       for (size_t a = 0; a < regions.size();) {
@@ -243,6 +273,12 @@ int main(int argc, char **argv) {
       host_counts[m] += w;
       return (size_t) __builtin_popcountll(m);
     };
+    auto count_intervals = [&](std::vector<uint32_t> &iv) {
+      if (!interval_stats || iv.empty()) return;
+      std::sort(iv.begin(), iv.end());
+      ++interval_counts[iv];
+    };
+    std::vector<uint32_t> hi_cnt, hi_idx;
     uint64_t cpt = 0;
     for (;;) {
       size_t n = 0;
@@ -253,33 +289,60 @@ int main(int argc, char **argv) {
       if (mm_annotate_batch(ctx, aln.data(), nh.data(), n, mm_reader_qid_bound(rd), 0) != MM_OK || mm_sync(ctx) != MM_OK) {
         std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
       }
-      if (read_stats) {
+      if (host_book) {
         hm.resize(n);
         if (mm_get_hit_masks(ctx, hm.data(), n) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        size_t hi_total = 0;
+        if (interval_stats) {
+          hi_cnt.resize(n);
+          if (mm_get_hit_intervals(ctx, hi_cnt.data(), nullptr, 0, &hi_total) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+          hi_idx.resize(hi_total ? hi_total : 1);
+          if (hi_total && mm_get_hit_intervals(ctx, hi_cnt.data(), hi_idx.data(), hi_total, &hi_total) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        }
+        size_t hi_off = 0;
         for (size_t i = 0; i < n; ++i) {
           if (hm[i] == ~0ull) continue;            // skipped by -y unique
           std::vector<uint8_t> regions;
           for (int e = 0; e < E; ++e) if (hm[i] >> e & 1) regions.push_back((uint8_t) e);
+          std::vector<uint32_t> intervals;
+          if (interval_stats) { intervals.assign(hi_idx.begin() + hi_off, hi_idx.begin() + hi_off + hi_cnt[i]); hi_off += hi_cnt[i]; }
           const uint32_t q = aln[i].qid, h = nh[i];
           if (h > 1 && strategy == MM_STRAT_DEFAULT) {   // :1669-1702
             auto it = pending.find(q);
-            if (it == pending.end()) { pending[q] = PendingRead{h - 1, h, regions}; ++h_reads; }
+            if (it == pending.end()) { pending[q] = PendingRead{h - 1, h, regions, intervals}; ++h_reads; }
             else {
               PendingRead &p = it->second;
               --p.remaining;
               p.regions.insert(p.regions.end(), regions.begin(), regions.end());
+              p.intervals.insert(p.intervals.end(), intervals.begin(), intervals.end());
               if (p.remaining == 0) {
                 if (!p.regions.empty()) {
                   print_read_stats(q, h, p.regions);
                   if (count_regions(p.regions, 1.0) == 1) ++h_rescued;
+                  count_intervals(p.intervals);
                 }
                 pending.erase(it);
               }
             }
           } else {                                       // :1703-1738
             if (!regions.empty()) {
-              print_read_stats(q, h, regions);
-              count_regions(regions, strategy == MM_STRAT_RATIO ? 1.0 / h : 1.0);
+              bool output = true;
+              if (strategy == MM_STRAT_RANDOM) {         // :1706-1726, libc rand() without srand, as the reference
+                output = false;
+                if (q >= rnd_seen.size()) rnd_seen.resize((size_t) q + 1024, false);
+                if (!rnd_seen[q]) {
+                  auto pc = rnd_choice.find(q);
+                  uint32_t chosen, seen_n;
+                  if (pc == rnd_choice.end()) { chosen = h ? (uint32_t) (grand.next() % h) : 0u; seen_n = 0; rnd_choice[q] = std::make_pair(chosen, seen_n); }
+                  else { chosen = pc->second.first; seen_n = ++pc->second.second; }
+                  if (seen_n == chosen) { output = true; rnd_choice.erase(q); rnd_seen[q] = true; }
+                }
+              }
+              if (output) {
+                print_read_stats(q, h, regions);
+                count_regions(regions, strategy == MM_STRAT_RATIO ? 1.0 / h : 1.0);
+                count_intervals(intervals);
+              }
             }
             ++h_reads;
           }
@@ -294,12 +357,16 @@ int main(int argc, char **argv) {
     mm_get_stats(ctx, st);
     std::vector<uint64_t> masks;
     std::vector<double> sums;
-    if (read_stats) {
-      for (auto &e : pending) {                          // EOF flush :1783-1792
-        if (e.second.regions.empty()) continue;
-        print_read_stats(e.first, e.second.raw, e.second.regions);
-        if (count_regions(e.second.regions, 1.0) == 1 && e.second.raw > 1) ++h_rescued;
+    if (host_book) {
+      for (auto &e : pending) {                          // EOF flush :1783-1800
+        if (!e.second.regions.empty()) {
+          print_read_stats(e.first, e.second.raw, e.second.regions);
+          if (count_regions(e.second.regions, 1.0) == 1 && e.second.raw > 1) ++h_rescued;
+        }
+        count_intervals(e.second.intervals);
       }
+    }
+    if (read_stats || strategy == MM_STRAT_RANDOM) {     // counts that depend on the host bookkeeping (-e rescue, rand())
       st[MM_STAT_READS] = h_reads; st[MM_STAT_RESCUED] = h_rescued;
       for (auto &e : host_counts) { masks.push_back(e.first); sums.push_back(e.second); }
     } else {
@@ -318,6 +385,27 @@ int main(int argc, char **argv) {
                 << "\t# hits:                        " << commas(st[MM_STAT_HITS]) << "\n"
                 << stat_line(st[MM_STAT_AMBIGUOUS], "# ambiguous hits:              ", st[MM_STAT_HITS])
                 << stat_line(st[MM_STAT_UNASSIGNED], "# unassigned hits:             ", st[MM_STAT_HITS]);
+    }
+    if (interval_stats) {                                // Counter::dump, :1819-1850
+      const uint8_t *iv_type = nullptr;
+      mm_annotation_intervals(an, nullptr, nullptr, nullptr, &iv_type, nullptr);
+      std::vector<std::pair<std::string, unsigned>> lines;
+      for (auto &p : interval_counts) {
+        std::vector<std::string> nm;
+        for (uint32_t i : p.first) nm.push_back(std::string(mm_annotation_interval_id(an, i)) + " (" + elem_names[iv_type[i]] + ")");
+        std::sort(nm.begin(), nm.end());
+        std::string joined;
+        for (size_t k = 0; k < nm.size(); ++k) joined += (k ? " -- " : "") + nm[k];
+        lines.emplace_back(joined, p.second);
+      }
+      std::sort(lines.begin(), lines.end());
+      std::string cur;
+      unsigned count = 0;
+      for (auto &ln : lines) {
+        if (ln.first == cur) count += ln.second;
+        else { if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n"; cur = ln.first; count = ln.second; }
+      }
+      if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n";
     }
     for (size_t r = 0; r < masks.size(); ++r) {          // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
       auto &col = table[masks[r]];
@@ -341,6 +429,7 @@ int main(int argc, char **argv) {
   }
   out.flush();
   if (read_stats) read_stats_out.close();
+  if (interval_stats) interval_stats_out.close();
   mm_ctx_destroy(ctx); mm_index_destroy(index); mm_annotation_free(an);
   std::cerr << "Successfully done." << std::endl;
   return 0;

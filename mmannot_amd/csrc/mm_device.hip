@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
     cUnique += __popcll(__ballot(processed && np == 1 && nh == 1));
     cMulti += __popcll(__ballot(grouped));
     cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
-    const bool counted = processed && !grouped && mask != 0;                       // mmannot.cpp:1704
+    const bool counted = processed && !grouped && mask != 0 && P.strategy != MM_STRAT_RANDOM;   // mmannot.cpp:1704 (random: the caller decides)
     u32 key = NO_KEY, pay = 0xFFFFu;
     if (grouped) {
       key = (u32) a.w;
@@ -1055,6 +1055,42 @@ __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restr
   }
 }
 
+// ----------------------------------------------------------------------------- -M: intervals behind each hit
+// EvaluationStructure::getIds (mmannot.cpp:1077-1081): for every element of the hit's final set, all intervals of that
+// element that passed the strand / overlap test during scan().  COUNT pass writes how many, FILL pass writes their
+// indices (in the reference's sorted interval vector) at the offsets an exclusive scan of the counts gives.
+template <int OVL, bool FILL>
+__global__ __launch_bounds__(256) void k_hit_intervals(const ProbeParams P, const u32 *__restrict__ actIdx, const int4 *__restrict__ aln, size_t n,
+                                                       const u64 *__restrict__ hm, u32 *__restrict__ cnt, const u32 *__restrict__ off,
+                                                       u32 *__restrict__ out) {
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+    const u64 mask = hm[i];
+    u32 c = 0;
+    if (mask != 0 && mask != ~0ull) {
+      const int4 a = aln[i];
+      const int s = a.x, e = a.y;
+      const int rec_strand = a.z & 1;
+      const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
+      Cand cd;
+      if (locate(P, (u32) a.z >> 1, s, cd)) {
+        u32 w = FILL ? off[i] : 0u;
+        for (u32 k = cd.a0; k < cd.a1; ++k) {
+          const int4 r = P.act[k];
+          u32 o;
+          if (((mask >> ((u32) r.z & 0xffu)) & 1ull) && iv_pass<OVL>(P, r, s, e, rstrand, o)) { if (FILL) out[w++] = actIdx[k]; ++c; }
+        }
+        for (u32 k = cd.i0; k < cd.i1; ++k) {
+          const int4 r = P.iv[k];
+          if (r.x > e) break;
+          u32 o;
+          if (((mask >> ((u32) r.z & 0xffu)) & 1ull) && iv_pass<OVL>(P, r, s, e, rstrand, o)) { if (FILL) out[w++] = k; ++c; }
+        }
+      }
+    }
+    if (!FILL) cnt[i] = c;
+  }
+}
+
 // ----------------------------------------------------------------------------- synthetic workload (bench / tests)
 struct SynthDev {
   u64 seed, first;
@@ -1121,6 +1157,7 @@ struct mm_index {
   uint2 *d_bins = nullptr;
   uint4 *d_chrInfo = nullptr;
   u64 *d_lineMask = nullptr;
+  u32 *d_actIdx = nullptr;
   uint4 *d_slots = nullptr;
   uint2 *d_flat = nullptr, *d_chrSlot = nullptr;
   int *d_longEnd = nullptr;
@@ -1144,6 +1181,7 @@ struct mm_ctx {
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
   size_t last_n = 0;
+  const int4 *last_aln = nullptr;   // device tuples of the last batch (valid until the next mm_annotate_batch)
   // persistent state
   GlobalTable G{};
   u64 *d_stats = nullptr, *d_walk = nullptr;
@@ -1243,6 +1281,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   ix->n_act = na;
   // records
   std::vector<int4> iv(n_iv), act(na ? na : 1);
+  std::vector<u32> actIdx(na ? na : 1);
   for (int c = 0; c < n_chromosomes; ++c) {
     if (!seen[c]) continue;
     int pm = -1;
@@ -1264,7 +1303,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     for (size_t i = 0; i < n_iv; ++i) {
       const int c = chr[i];
       const u32 b0 = ((u32) start[i] >> shift) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> shift, nBins[c] - 1);
-      for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) act[cur[binBase[c] + b]++] = iv[i];
+      for (u32 b = b0; b <= b1 && b1 != 0xFFFFFFFFu; ++b) { actIdx[cur[binBase[c] + b]] = (u32) i; act[cur[binBase[c] + b]++] = iv[i]; }
     }
   }
   // ---- compact slot index (see slot_walk)
@@ -1357,6 +1396,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   hipError_t e;
   if ((e = up((void **) &ix->d_iv, iv.data(), n_iv * sizeof(int4))) != hipSuccess ||
       (e = up((void **) &ix->d_act, act.data(), na * sizeof(int4))) != hipSuccess ||
+      (e = up((void **) &ix->d_actIdx, actIdx.data(), na * sizeof(u32))) != hipSuccess ||
       (e = up((void **) &ix->d_bins, bins.data(), nbt * sizeof(uint2))) != hipSuccess ||
       (e = up((void **) &ix->d_chrInfo, chrInfo.data(), (size_t) n_chromosomes * sizeof(uint4))) != hipSuccess ||
       (e = up((void **) &ix->d_lineMask, ix->lineMask, 64 * sizeof(u64))) != hipSuccess ||
@@ -1373,7 +1413,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
 
 extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
-  (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_bins);
+  (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
   delete ix;
 }
@@ -1397,8 +1437,9 @@ static void ctx_free_batch(mm_ctx *c) {
 extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options *opt, void *stream) {
   if (!out || !ix || !opt) return fail(MM_ERR_ARG, "mm_ctx_create: null argument");
   *out = nullptr;
-  if (opt->strategy == MM_STRAT_RANDOM)
-    return fail(MM_ERR_ARG, "mm_ctx_create: -y random replays libc rand() in file order and is not a device strategy");
+  if (opt->strategy == MM_STRAT_RANDOM && !opt->keep_hit_masks)
+    return fail(MM_ERR_ARG, "mm_ctx_create: -y random replays libc rand() in file order (mmannot.cpp:1706-1726): the device only provides "
+                            "the per-hit element sets and counters for it, so keep_hit_masks is required");
   if (opt->strategy < 0 || opt->strategy > MM_STRAT_RATIO || opt->overlap_mode < 0 || opt->overlap_mode > MM_OVL_NT ||
       opt->strandedness < 0 || opt->strandedness > MM_STRANDED_R)
     return fail(MM_ERR_ARG, "mm_ctx_create: bad option value");
@@ -1558,6 +1599,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
   }
   HIPCHK(hipGetLastError());
   c->last_n = n;
+  c->last_aln = d_aln;
   if (need_groups) {
     const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
     {
@@ -1668,6 +1710,47 @@ extern "C" int mm_get_hit_masks(mm_ctx *c, uint64_t *out, size_t n) {
   if (n > c->last_n) return fail(MM_ERR_ARG, "mm_get_hit_masks: n exceeds the last batch");
   HIPCHK(hipMemcpyAsync(out, c->d_hm, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+extern "C" int mm_get_hit_intervals(mm_ctx *c, uint32_t *counts, uint32_t *idx, size_t cap, size_t *total) {
+  if (!c || !counts || !total) return fail(MM_ERR_ARG, "mm_get_hit_intervals: null argument");
+  if (!c->opt.keep_hit_masks) return fail(MM_ERR_STATE, "mm_get_hit_intervals: context created without keep_hit_masks");
+  const size_t n = c->last_n;
+  *total = 0;
+  if (n == 0) return MM_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  ProbeParams P;
+  fill_params(c, P);
+  const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
+  u32 *d_cnt = c->d_gkey, *d_off = c->d_gpay;   // free between batches
+#define MM_LAUNCH_HI(FILLV, OUTP)                                                                                              \
+  switch (c->opt.overlap_mode) {                                                                                              \
+    case MM_OVL_INCLUSION: hipLaunchKernelGGL((k_hit_intervals<MM_OVL_INCLUSION, FILLV>), dim3(grid), dim3(256), 0, c->stream, P, c->ix->d_actIdx, c->last_aln, n, c->d_hm, d_cnt, d_off, OUTP); break; \
+    case MM_OVL_PC: hipLaunchKernelGGL((k_hit_intervals<MM_OVL_PC, FILLV>), dim3(grid), dim3(256), 0, c->stream, P, c->ix->d_actIdx, c->last_aln, n, c->d_hm, d_cnt, d_off, OUTP); break; \
+    default: hipLaunchKernelGGL((k_hit_intervals<MM_OVL_NT, FILLV>), dim3(grid), dim3(256), 0, c->stream, P, c->ix->d_actIdx, c->last_aln, n, c->d_hm, d_cnt, d_off, OUTP); \
+  }
+  MM_LAUNCH_HI(false, (u32 *) nullptr)
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<u32> off(n);
+  u64 tot = 0;
+  for (size_t i = 0; i < n; ++i) { off[i] = (u32) tot; tot += counts[i]; }
+  *total = (size_t) tot;
+  if (!idx || tot == 0) return MM_OK;
+  if (tot > cap) return fail(MM_ERR_ARG, "mm_get_hit_intervals: capacity too small");
+  if (tot >= 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_get_hit_intervals: too many intervals in one batch");
+  u32 *d_out = nullptr;
+  HIPCHK(hipMalloc((void **) &d_out, tot * 4));
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  MM_LAUNCH_HI(true, d_out)
+#undef MM_LAUNCH_HI
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(idx, d_out, tot * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void) hipFree(d_out);
+  if (e != hipSuccess) return fail(MM_ERR_HIP, std::string("mm_get_hit_intervals: ") + hipGetErrorString(e));
   return MM_OK;
 }
 

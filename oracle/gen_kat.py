@@ -71,7 +71,8 @@ KATS["E9_distance"] = dict(gtf=GTF_E9, cfg="Vicinity:\npc:gene\nOrder:\npc:gene\
 KATS["E10_rescue"] = dict(gtf=GTF_ABC, cfg=CFG_ABC, bam=[rec("r", 0, 1100, nh=4), rec("r", 0, 1200, nh=4), rec("r", 0, 3100, nh=4), rec("r", 0, 1300, nh=4),
                                                          rec("q", 0, 1100, nh=2), rec("q", 0, 5100, nh=2), rec("u", 0, 5200)],
                           runs=[["-s", "U", "-e", "75", "-m", "$M"], ["-s", "U", "-e", "80", "-m", "$M"], ["-s", "U", "-e", "75"], ["-s", "U", "-m", "$M"],
-                                ["-s", "U", "-e", "50", "-m", "$M", "-y", "ratio"]])
+                                ["-s", "U", "-e", "50", "-m", "$M", "-y", "ratio"], ["-s", "U", "-M", "$MM"], ["-s", "U", "-m", "$M", "-M", "$MM", "-e", "60"],
+                                ["-s", "U", "-y", "random"], ["-s", "U", "-y", "random", "-m", "$M", "-M", "$MM"]])
 # BWA-style XA alternatives: equal-NM alternatives are replayed as further reads, nHits = alternatives + 1; tag order matters
 KATS["X1_xa"] = dict(gtf=GTF_ABC, cfg=CFG_ABC,
                      bam=[rec("x1", 0, 1100, extra=tagC("NM", 1) + tagZ("XA", "chr1,-3100,50M,1;chr1,+5100,50M,2;chrZ,+10,50M,1;")),
@@ -85,7 +86,14 @@ SAM = ("@HD\tVN:1.0\n@SQ\tSN:chr1\tLN:100000\n"
        "s3\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\tNH:i:1\n"
        "s4\t0\tchr1\t1200\t255\t*\t*\t0\t0\t*\t*\tNM:i:0\n"
        "s5\t0\tchr1\t1950\t255\t10M100N50M\t*\t0\t0\t*\t*\tNM:i:0\tXA:Z:chr1,+1300,50M,0;\n")
-KATS["S1_sam"] = dict(gtf=GTF_ABC, cfg=CFG_ABC, sam=SAM, runs=[["-s", "U"], ["-s", "U", "-l", "0.5"]])
+KATS["S1_sam"] = dict(gtf=GTF_ABC, cfg=CFG_ABC, sam=SAM, runs=[["-s", "U"], ["-s", "U", "-l", "0.5"], ["-s", "U", "-M", "$MM"]])
+# -M on overlapping intervals of one element (several intervals behind one hit) and on multi-hit reads
+GTF_M = ("chr1\tsrc\tfeatA\t1000\t2000\t.\t+\t.\tgene_id \"A1\";\nchr1\tsrc\tfeatA\t1200\t2500\t.\t+\t.\tgene_id \"A2\";\n"
+         "chr1\tsrc\tfeatB\t3000\t4000\t.\t-\t.\tgene_id \"B\";\nchr1\tsrc\tfeatA\t3100\t3300\t.\t+\t.\tgene_id \"A3\";\n")
+KATS["M1_intervals"] = dict(gtf=GTF_M, cfg="Order:\nsrc:featA,src:featB\n",
+                            bam=[rec("m1", 0, 1300), rec("m2", 0, 1100), rec("m3", 0, 3150, nh=2), rec("m3", 0, 1300, nh=2), rec("m4", 0, 3150), rec("m5", 0, 3500),
+                                 rec("m6", 0, 1300, nh=3), rec("m6", 0, 9000, nh=3)],
+                            runs=[["-s", "U", "-M", "$MM"], ["-s", "U", "-l", "10", "-M", "$MM", "-m", "$M"]])
 
 
 def main():
@@ -107,19 +115,21 @@ def main():
         tmp = tempfile.mkdtemp(prefix="mmkat")
         for run in k["runs"]:
             mfile = os.path.join(tmp, "m.txt")
-            args = [a if a != "$M" else mfile for a in run]
+            mmfile = os.path.join(tmp, "mm.txt")
+            args = [mfile if a == "$M" else (mmfile if a == "$MM" else a) for a in run]
             for variant, tag in (("mmannot_dump", "verbatim"), ("mmannot_patched_dump", "patched")):
                 a2 = list(args)
                 if tag == "patched":                 # the patched reference gives -s F/R their intended meaning
                     a2[a2.index("-s") + 1] = "F"
                 dump = os.path.join(tmp, "d.txt")
                 tsv = os.path.join(tmp, "t.tsv")
-                for f in (mfile, dump, tsv):
+                for f in (mfile, mmfile, dump, tsv):
                     if os.path.exists(f):
                         os.remove(f)
                 rc, so, se = mo.run_ref(variant, ["-a", os.path.join(d, "a.gtf"), "-r", reads, "-c", os.path.join(d, "c.cfg"), "-o", tsv] + a2, dump=dump, cwd=tmp)
                 iv, hits = mo.parse_dump(dump) if os.path.exists(dump) else ({}, dict(name=[], chr_name=[], start=[], end=[], strand=[], nh=[], mask=[]))
-                cases.append(dict(args=[a if a != mfile else "$M" for a in a2], variant=tag, rc=rc, table=open(tsv).read() if os.path.exists(tsv) else None,
+                cases.append(dict(args=["$M" if a == mfile else ("$MM" if a == mmfile else a) for a in a2], variant=tag,
+                                  mmfile=open(mmfile).read() if (os.path.exists(mmfile) and "$MM" in run) else None, rc=rc, table=open(tsv).read() if os.path.exists(tsv) else None,
                                   stderr=se.replace(d, "$D").replace(tmp, "$T"), mfile=open(mfile).read() if (os.path.exists(mfile) and "$M" in run) else None,
                                   hits=dict(name=hits["name"], chr=hits["chr_name"], start=hits["start"], end=hits["end"], strand=hits["strand"],
                                             nh=hits["nh"], mask=[int(m) for m in hits["mask"]])))

@@ -25,7 +25,7 @@ WORKLOADS = {
     "hs38": dict(shape="hs38", seed=6, scale=0.01, n=80000, read_len=100, nh_max=20, scatter=12, rseed=12),
 }
 RUNS = [["-s", "F"], ["-s", "R", "-l", "0.5"], ["-s", "U", "-y", "unique"], ["-s", "F", "-y", "ratio"], ["-s", "F", "-l", "30", "-d", "300", "-D", "50"],
-        ["-s", "R", "-y", "ratio", "-l", "1"]]
+        ["-s", "R", "-y", "ratio", "-l", "1"], ["-s", "F", "-M", "$MM"], ["-s", "U", "-y", "random"], ["-s", "F", "-l", "0.3", "-m", "$M", "-M", "$MM", "-e", "60"]]
 
 
 def make_inputs(w, d):
@@ -58,8 +58,14 @@ def main():
         cases = []
         for run in RUNS:
             tsv = os.path.join(d, "t.tsv")
-            rc, so, se = mo.run_ref("mmannot_patched", ["-a", gtf, "-r", bam, "-c", cfg, "-o", tsv] + run)
-            cases.append(dict(args=run, rc=rc, table=open(tsv).read(), stderr=se.replace(d, "$D")))
+            mf, mmf = os.path.join(d, "m.txt"), os.path.join(d, "mm.txt")
+            for f in (mf, mmf):
+                if os.path.exists(f):
+                    os.remove(f)
+            args = [mf if a == "$M" else (mmf if a == "$MM" else a) for a in run]
+            rc, so, se = mo.run_ref("mmannot_patched", ["-a", gtf, "-r", bam, "-c", cfg, "-o", tsv] + args)
+            cases.append(dict(args=run, rc=rc, table=open(tsv).read(), stderr=se.replace(d, "$D"),
+                              mfile=open(mf).read() if "$M" in run else None, mmfile=open(mmf).read() if "$MM" in run else None))
             print("synth_e2e", name, run, rc, cases[-1]["table"].count("\n") - 1, "rows", file=sys.stderr)
         out[name] = dict(workload=w, cases=cases)
     json.dump(out, open(os.path.join(GOLD, "cases.json"), "w"), indent=1)

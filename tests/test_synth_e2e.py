@@ -29,6 +29,8 @@ def test_host_plus_oracle(oracle, inputs, name):
     import mmannot_amd.api as api
     d, gtf, cfg, bam = inputs[name]
     for c in CASES[name]["cases"]:
+        if "-m" in c["args"] or "-M" in c["args"] or "random" in c["args"]:
+            continue                     # host bookkeeping of the CLI: covered by test_cli
         o = gu.parse_args(c["args"])
         an = api.Annotation(cfg, gtf, o["d"], o["D"])
         dec = api.ReadsDecoder(bam, an, unique_only=(o["strategy"] == "unique"))
@@ -47,7 +49,13 @@ def test_cli(gpu_lib, inputs, name):
     d, gtf, cfg, bam = inputs[name]
     for c in CASES[name]["cases"]:
         out = os.path.join(d, "t.tsv")
-        p = subprocess.run([CLI, "-a", gtf, "-r", bam, "-c", cfg, "-o", out] + c["args"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        mf, mmf = os.path.join(d, "m_out.txt"), os.path.join(d, "mm_out.txt")
+        args = [mf if a == "$M" else (mmf if a == "$MM" else a) for a in c["args"]]
+        p = subprocess.run([CLI, "-a", gtf, "-r", bam, "-c", cfg, "-o", out] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert p.returncode == c["rc"], p.stderr.decode()
         assert open(out).read() == c["table"], c["args"]
         assert p.stderr.decode().replace(d, "$D") == c["stderr"], c["args"]
+        if c.get("mfile") is not None:
+            assert sorted(open(mf).read().splitlines()) == sorted(c["mfile"].splitlines())
+        if c.get("mmfile") is not None:
+            assert open(mmf).read() == c["mmfile"]
