@@ -63,9 +63,22 @@ def build_cli(force: bool = False, verbose: bool = False):
     return exe
 
 
+def build_addnh(force: bool = False, verbose: bool = False):
+    """mmannot-amd-addnh: the companion SAM filter (host only)."""
+    src = os.path.join(CSRC, "cli_addnh.cpp")
+    exe = os.path.join(PKG, "mmannot-amd-addnh")
+    if os.path.exists(src) and (force or _stale(exe, [src])):
+        cmd = ["g++", "-O2", "-std=c++17", "-o", exe, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return exe
+
+
 def build_all(force: bool = False, verbose: bool = False):
     build_lib(force, verbose)
     build_cli(force, verbose)
+    build_addnh(force, verbose)
 
 
 if __name__ == "__main__":

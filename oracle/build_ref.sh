@@ -26,6 +26,10 @@ if [ ! -f "$SRC" ]; then
   exit 0
 fi
 mkdir -p "$OUT"
+if [ -x "$OUT/mmannot_patched_dump" ] && [ -x "$OUT/addNH" ] && [ "$OUT/mmannot_patched_dump" -nt "$SRC" ] && [ "$OUT/mmannot_patched_dump" -nt "${BASH_SOURCE[0]}" ]; then
+  echo "build_ref.sh: oracle/_ref is up to date" >&2
+  exit 0
+fi
 FLAGS="-DMMSTANDALONE -Wpedantic -std=c++11 -pthread -O3"
 
 # anchors must match exactly once, otherwise the reference changed under us
@@ -48,4 +52,5 @@ g++ "$SRC" $FLAGS -lz -o "$OUT/mmannot"
 sed -e "$SED_PATCH" "$SRC" | g++ -x c++ - $FLAGS -lz -o "$OUT/mmannot_patched"
 sed -e "$SED_IV" -e "$SED_HIT" "$SRC" | g++ -x c++ - $FLAGS -lz -o "$OUT/mmannot_dump"
 sed -e "$SED_PATCH" -e "$SED_IV" -e "$SED_HIT" "$SRC" | g++ -x c++ - $FLAGS -lz -o "$OUT/mmannot_patched_dump"
+if [ -f "$REF/addNH.cpp" ]; then g++ "$REF/addNH.cpp" $FLAGS -lz -o "$OUT/addNH"; fi
 echo "build_ref.sh: built $(ls "$OUT" | tr '\n' ' ')" >&2
