@@ -561,98 +561,44 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
   lds_table_flush(T, G);
 }
 
-// ----------------------------------------------------------------------------- ordered compaction of (key, index) pairs
+// ----------------------------------------------------------------------------- grouping pipeline: tiles of (key, payload) pairs
 #define RS_THREADS 256
 #define RS_ROUNDS 16
 #define RS_TILE (RS_THREADS * RS_ROUNDS)
 
-__global__ __launch_bounds__(RS_THREADS) void k_flag_count(const u32 *__restrict__ gkey, size_t n, u32 *__restrict__ tileCnt) {
-  __shared__ u32 tot;
-  if (threadIdx.x == 0) tot = 0;
-  __syncthreads();
-  const size_t lo = (size_t) blockIdx.x * RS_TILE;
-  u32 c = 0;
-  for (int r = 0; r < RS_ROUNDS; ++r) {
-    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
-    c += (i < n && gkey[i] != NO_KEY) ? 1u : 0u;
-  }
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
-  __syncthreads();
-  if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
-}
-
-// exclusive scan of a[0..n) in place by one workgroup; total -> *total
-__global__ __launch_bounds__(1024) void k_scan_single(u32 *__restrict__ a, u32 n, u32 *__restrict__ total) {
-  __shared__ u32 wsum[16];
-  __shared__ u32 carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (u32 base = 0; base < n; base += 1024) {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < n) ? a[i] : 0;
-    u32 x = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 y = __shfl_up(x, off);
-      if ((int) lane >= off) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    u32 woff = 0;
-    for (u32 k = 0; k < w; ++k) woff += wsum[k];
-    const u32 c = carry;
-    if (i < n) a[i] = c + woff + x - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c + woff + x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && total) *total = carry;
-}
-
-__global__ __launch_bounds__(RS_THREADS) void k_emit_pairs(const u32 *__restrict__ gkey, const u32 *__restrict__ gpay, size_t n,
-                                                           const u32 *__restrict__ tileOff, const u32 *__restrict__ info, int rebase,
-                                                           u32 *__restrict__ keys, u32 *__restrict__ vals) {
-  __shared__ u32 wcnt[4];
-  __shared__ u32 run;
-  if (threadIdx.x == 0) run = tileOff[blockIdx.x];
-  __syncthreads();
-  const size_t lo = (size_t) blockIdx.x * RS_TILE;
-  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const u32 qmin = rebase ? ~info[INFO_QINV] : 0u;
-  const bool by_index = rebase && info[INFO_BIGNH];
-  for (int r = 0; r < RS_ROUNDS; ++r) {
-    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
-    u32 k = NO_KEY;
-    if (i < n) k = gkey[i];
-    const bool f = (k != NO_KEY);
-    const u64 bal = __ballot(f);
-    const u32 rank = (u32) __popcll(bal & ((1ull << lane) - 1));
-    if (lane == 0) wcnt[w] = (u32) __popcll(bal);
-    __syncthreads();
-    u32 off = run;
-    for (u32 q = 0; q < w; ++q) off += wcnt[q];
-    if (f) { keys[off + rank] = k - qmin; vals[off + rank] = by_index ? (u32) i : gpay[i]; }
-    __syncthreads();
-    if (threadIdx.x == 0) run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
-  }
-}
-
 // ----------------------------------------------------------------------------- stable LSD radix sort (8-bit digits)
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ info, int shift, int fixed_bits,
-                                                        u32 *__restrict__ hist, u32 nblk) {
+// First pass (FIRST = true) reads the batch's records where k_probe left them: key gkey[i] (NO_KEY = not in the
+// grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
+// payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
+// in file order within each digit, and k_rs_scan_tot publishes their number (INFO_M) for the following passes.
+template <bool FIRST>
+__device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *__restrict__ vin, const u32 *__restrict__ info, size_t i, size_t n,
+                                        int rebase, u32 &k, u32 &v) {
+  if (FIRST) {
+    if (i >= n) return false;
+    const u32 g = kin[i];
+    if (g == NO_KEY) return false;
+    k = rebase ? g - ~info[INFO_QINV] : g;
+    v = (rebase && info[INFO_BIGNH]) ? (u32) i : vin[i];
+    return true;
+  }
+  if (i >= info[INFO_M]) return false;
+  k = kin[i]; v = vin[i];
+  return true;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ info,
+                                                        size_t n, int rebase, int shift, int fixed_bits, u32 *__restrict__ hist, u32 nblk) {
   __shared__ u32 h[256];
-  if (shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
+  if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
   h[threadIdx.x] = 0;
   __syncthreads();
-  const u32 M = info[INFO_M];
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
-  if (lo < M) {
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-      const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
-      if (i < M) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-    }
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
+    u32 k, v;
+    if (rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v)) atomicAdd(&h[(k >> shift) & 255u], 1u);
   }
   __syncthreads();
   hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -663,7 +609,7 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u3
                                                       const u32 *__restrict__ info, int shift, int fixed_bits) {
   __shared__ u32 wsum[4];
   __shared__ u32 carry;
-  if (shift >= batch_key_bits(info, fixed_bits)) return;
+  if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
   u32 *row = hist + (size_t) blockIdx.x * nblk;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -689,14 +635,15 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u3
   if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, const u32 *__restrict__ info, int shift, int fixed_bits) {
+__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, u32 *__restrict__ info, int shift, int fixed_bits) {
   __shared__ u32 s[256];
-  if (shift >= batch_key_bits(info, fixed_bits)) return;
+  if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
   s[threadIdx.x] = rowTotal[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 acc = 0;
     for (int d = 0; d < 256; ++d) { const u32 v = s[d]; s[d] = acc; acc += v; }
+    if (shift == 0) info[INFO_M] = acc;   // the first pass compacts: this is the number of pairs in the pipeline
   }
   __syncthreads();
   rowTotal[threadIdx.x] = s[threadIdx.x];
@@ -711,30 +658,32 @@ __global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal,
 //      at their tile-local sorted position in LDS;
 //   D. the sorted tile is copied out: consecutive lanes write consecutive addresses inside each digit run, so
 //      the scatter reaches memory as 64-B-and-longer segments instead of isolated 4-B stores.
+template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
-                                                           u32 *__restrict__ vout, const u32 *__restrict__ info, int shift, int fixed_bits,
-                                                           const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
+                                                           u32 *__restrict__ vout, const u32 *__restrict__ info, size_t n, int rebase, int shift,
+                                                           int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
   __shared__ u32 lkey[RS_TILE];
   __shared__ u32 lval[RS_TILE];
   __shared__ u32 cntw[4][256];   // A: digit counts per wave; C: running tile-local offset per wave
   __shared__ u32 goff[256];      // global position of digit d's first pair of this tile, minus its tile-local offset
   __shared__ u32 wsum[4];
-  if (shift >= batch_key_bits(info, fixed_bits)) return;
-  const u32 M = info[INFO_M];
+  __shared__ u32 tcountS;
+  if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
-  if (lo >= M) return;
+  const size_t lim = FIRST ? n : (size_t) info[INFO_M];
+  if (lo >= lim) return;
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const u32 tcount = (u32) min((size_t) RS_TILE, (size_t) M - lo);
   cntw[0][t] = 0; cntw[1][t] = 0; cntw[2][t] = 0; cntw[3][t] = 0;
   __syncthreads();
   u32 kreg[RS_ROUNDS], vreg[RS_ROUNDS];
+  u32 vmask = 0;                     // which of this lane's 16 pairs exist (the first pass filters on the fly)
   const u32 wbase = w * (RS_TILE / 4);
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const u32 li = wbase + (u32) r * 64u + lane;
     kreg[r] = 0; vreg[r] = 0;
-    if (li < tcount) {
-      kreg[r] = kin[lo + li]; vreg[r] = vin[lo + li];
+    if (rs_load<FIRST>(kin, vin, info, lo + li, n, rebase, kreg[r], vreg[r])) {
+      vmask |= 1u << r;
       atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
     }
   }
@@ -751,14 +700,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     __syncthreads();
     u32 loff = x - tot;
     for (u32 q = 0; q < w; ++q) loff += wsum[q];
+    if (t == 255) tcountS = loff + tot;                  // number of pairs this tile holds
     goff[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x] - loff;
     cntw[0][t] = loff; cntw[1][t] = loff + c0; cntw[2][t] = loff + c0 + c1; cntw[3][t] = loff + c0 + c1 + c2;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {  // C: wave-private, LDS operations of one wave execute in program order
-    const u32 li = wbase + (u32) r * 64u + lane;
-    const bool valid = li < tcount;
+    const bool valid = (vmask >> r) & 1u;
     const u32 d = (kreg[r] >> shift) & 255u;
     u64 peers = __ballot(valid);
 #pragma unroll
@@ -773,6 +722,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     if (valid) { lkey[pos] = kreg[r]; lval[pos] = vreg[r]; }
   }
   __syncthreads();
+  const u32 tcount = tcountS;
   for (u32 i = t; i < tcount; i += RS_THREADS) {  // D
     const u32 k = lkey[i];
     const u32 g = goff[(k >> shift) & 255u] + i;
@@ -1543,14 +1493,20 @@ static int bits_for(u64 bound) {
 // Stable LSD sort of the batch's pairs (kA,vA) on the low `max_bits` key bits.  The passes the batch's actual key
 // range does not need return immediately (device-side decision, no host round trip); the consumer works out from
 // the same device scalars whether the result sits in A or B.
-static int sort_pairs(mm_ctx *c, size_t n_cap, int max_bits, int fixed_bits) {
-  const u32 nblk = (u32) ((n_cap + RS_TILE - 1) / RS_TILE);
-  u32 *kin = c->d_kA, *vin = c->d_vA, *kout = c->d_kB, *vout = c->d_vB;
-  for (int shift = 0; shift < max_bits; shift += 8) {
-    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, c->d_M, shift, fixed_bits, c->d_hist, nblk);
+static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int rebase) {
+  const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
+  // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
+  hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
+  hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, 0, fixed_bits);
+  hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, 0, fixed_bits);
+  hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
+                     fixed_bits, c->d_hist, c->d_rowTot, nblk);
+  u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
+  for (int shift = 8; shift < max_bits; shift += 8) {
+    hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
     hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, shift, fixed_bits);
     hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, shift, fixed_bits);
-    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, shift, fixed_bits,
+    hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk);
     std::swap(kin, kout); std::swap(vin, vout);
   }
@@ -1601,17 +1557,9 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
   c->last_n = n;
   c->last_aln = d_aln;
   if (need_groups) {
-    const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
-    {
-      PhaseTimer t(c, MM_PHASE_COMPACT);
-      hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, n, c->d_tile);
-      hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, c->stream, c->d_tile, nblk, c->d_M);
-      hipLaunchKernelGGL(k_emit_pairs, dim3(nblk), dim3(RS_THREADS), 0, c->stream, gkey, c->d_gpay, n, c->d_tile, c->d_M, dflt ? 1 : 0,
-                         c->d_kA, c->d_vA);
-    }
     {
       PhaseTimer t(c, MM_PHASE_SORT);
-      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, dflt ? 0 : 16);
+      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, dflt ? 0 : 16, dflt ? 1 : 0);
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
