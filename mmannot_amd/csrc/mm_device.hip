@@ -894,6 +894,7 @@ __global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem,
 #define RATIO_PER_THREAD 16
 #define RATIO_SERIAL_STEP 1024      // a chunk that cannot be reduced is replayed this many terms at a time
 #define RATIO_CHUNK (RATIO_THREADS * RATIO_PER_THREAD)
+#define RATIO_SLOTS_PER_WG 128
 
 __global__ __launch_bounds__(256) void k_seg_bounds(const u32 *__restrict__ skeys, const u32 *__restrict__ info, u32 *__restrict__ segLo,
                                                     u32 *__restrict__ segHi) {
@@ -921,83 +922,204 @@ __device__ __forceinline__ u64 ratio_inc(u32 nh, int k) {
   return q + (rem > half ? 1ull : 0ull);
 }
 
+// Tile summaries for long rows: every 16384-term tile of the sorted stream that lies inside one row gets the sum of
+// its integer increments, computed for the binade the row's sum is in when the batch starts.  The whole GPU works on
+// this; k_ratio_rows then consumes a tile in O(1) as long as the binade is still the same and the tile neither holds a
+// tie-capable / infinite term nor leaves the binade, and falls back to its own exact chunk path otherwise.
+__global__ __launch_bounds__(256) void k_ratio_tiles(const u32 *__restrict__ skeys, const u32 *__restrict__ svals, const u32 *__restrict__ info,
+                                                     GlobalTable G, u64 *__restrict__ tileTot, int *__restrict__ tileK) {
+  // tileTot[2T], tileK[2T]: summary for the binade k the row is in now; [2T+1]: for binade k+1 (a long row crosses
+  // into the next binade at most once per batch, and the tiles behind the crossing then still have a summary)
+  __shared__ u64 wsum[2][4];
+  __shared__ u32 wbad[2][4];
+  const u32 M = info[INFO_M];
+  const size_t lo = (size_t) blockIdx.x * RATIO_CHUNK;
+  if (lo >= M) return;
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int k = 0x7ffffffe;                                        // "no summary"
+  if (lo + RATIO_CHUNK <= M) {
+    const u32 key0 = skeys[lo], key1 = skeys[lo + RATIO_CHUNK - 1];
+    if (key0 == key1) {
+      const u64 bs = (u64) __double_as_longlong(G.sum[key0]);
+      const int E = (int) ((bs >> 52) & 0x7FF);
+      if (E != 0 && E != 0x7FF && !(bs >> 63)) k = E - 1023;
+    }
+  }
+  if (k == 0x7ffffffe) { if (t < 2) tileK[2 * blockIdx.x + t] = k; return; }   // block-uniform
+  u64 acc0 = 0, acc1 = 0;
+  u32 bad0 = 0, bad1 = 0;
+  for (u32 i = t; i < RATIO_CHUNK; i += 256) {
+    const u32 nh = svals[lo + i];
+    const u64 i0 = ratio_inc(nh, k), i1 = ratio_inc(nh, k + 1);
+    if (i0 == RATIO_SENTINEL) bad0 = 1; else acc0 += i0;    // inc < 2^52, 64 terms per lane, 64 lanes: below 2^64
+    if (i1 == RATIO_SENTINEL) bad1 = 1; else acc1 += i1;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    acc0 += __shfl_down(acc0, off); bad0 |= __shfl_down(bad0, off);
+    acc1 += __shfl_down(acc1, off); bad1 |= __shfl_down(bad1, off);
+  }
+  if (lane == 0) { wsum[0][w] = acc0; wbad[0][w] = bad0; wsum[1][w] = acc1; wbad[1][w] = bad1; }
+  __syncthreads();
+  if (t < 2) {
+    u64 tot = 0; u32 b = 0;
+    for (int q = 0; q < 4; ++q) { if (wsum[t][q] >= (1ull << 53)) b = 1; else tot += wsum[t][q]; b |= wbad[t][q]; }
+    tileTot[2 * blockIdx.x + t] = tot;
+    tileK[2 * blockIdx.x + t] = b ? 0x7ffffffe : k + (int) t;
+  }
+}
+
 __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restrict__ svals, const u32 *__restrict__ segLo,
-                                                              const u32 *__restrict__ segHi, GlobalTable G) {
+                                                              const u32 *__restrict__ segHi, GlobalTable G, const u64 *__restrict__ tileTot,
+                                                              const int *__restrict__ tileK) {
   __shared__ u64 lut[RATIO_LUT];
   __shared__ u64 wsum[RATIO_THREADS / 64];
   __shared__ u32 wflag[RATIO_THREADS / 64];
   __shared__ double sS;
   __shared__ int sK, sSerial;
+  __shared__ int sTileK[RATIO_LUT], sTileK2[RATIO_LUT];
+  __shared__ u64 sTot2[RATIO_LUT];
+  __shared__ u32 sUsed;
+  __shared__ u64 sBefore;
+  __shared__ u32 sLo[RATIO_SLOTS_PER_WG], sHi[RATIO_SLOTS_PER_WG];
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   int kLut = 0x7fffffff;
-  for (u32 slot = blockIdx.x; slot < GT_CAP; slot += gridDim.x) {
-    const u32 lo = segLo[slot], hi = segHi[slot];
+  // this workgroup's slots: one coalesced read of their segment bounds instead of a dependent load per slot
+  const u32 slot0 = blockIdx.x * RATIO_SLOTS_PER_WG;
+  if (t < RATIO_SLOTS_PER_WG) { sLo[t] = segLo[slot0 + t]; sHi[t] = segHi[slot0 + t]; }
+  __syncthreads();
+  for (u32 si = 0; si < RATIO_SLOTS_PER_WG; ++si) {
+    const u32 slot = slot0 + si;
+    const u32 lo = sLo[si], hi = sHi[si];
     if (hi <= lo) continue;                                  // block-uniform
     if (t == 0) sS = G.sum[slot];
     __syncthreads();
     for (u32 cb = lo; cb < hi;) {
-      u32 cn = min((u32) RATIO_CHUNK, hi - cb);
+      u32 cn = min(hi - cb, (u32) RATIO_CHUNK - (cb % RATIO_CHUNK));   // chunks end on tile boundaries
+      if (cn == RATIO_CHUNK) {
+        // Full tiles ahead: consume their precomputed summaries (k_ratio_tiles) while they stay valid.
+        const u32 T0 = cb / RATIO_CHUNK, nT = min((hi - cb) / RATIO_CHUNK, (u32) RATIO_LUT);
+        __syncthreads();
+        for (u32 i = t; i < nT; i += RATIO_THREADS) {           // lut doubles as staging; tot2 holds the next binade's sums
+          lut[i] = tileTot[2 * (T0 + i)]; sTileK[i] = tileK[2 * (T0 + i)];
+          sTot2[i] = tileTot[2 * (T0 + i) + 1]; sTileK2[i] = tileK[2 * (T0 + i) + 1];
+        }
+        kLut = 0x7fffffff;
+        __syncthreads();
+        if (t == 0) {
+          double S = sS;
+          u64 bs = (u64) __double_as_longlong(S);
+          int E = (int) ((bs >> 52) & 0x7FF);
+          u32 used = 0;
+          if (E != 0 && E != 0x7FF && !(bs >> 63)) {
+            const int k = E - 1023;
+            u64 N = (bs & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+            for (; used < nT; ++used) {
+              const u64 add = (sTileK[used] == k) ? lut[used] : ((sTileK2[used] == k) ? sTot2[used] : ~0ull);
+              if (add == ~0ull || N + add >= (1ull << 53)) break;
+              N += add;
+            }
+            sS = __longlong_as_double((long long) ((((u64) E) << 52) | (N & 0xFFFFFFFFFFFFFull)));
+          }
+          sUsed = used;
+        }
+        __syncthreads();
+        const u32 used = sUsed;
+        __syncthreads();
+        if (used) { cb += used * RATIO_CHUNK; continue; }     // block-uniform
+      }
+      // Exact chunk step.  Every thread takes 16 consecutive terms; a block-wide prefix scan of the integer increments
+      // finds the first term that cannot be applied as an integer step: one that would leave the binade, one whose
+      // rounding is an exact tie, or an infinite one (and the very first term of a row, S = 0).  Everything before it is
+      // applied at once; that single term is added with a real IEEE add; the next step starts behind it.
       if (t == 0) {
-        const double S = sS;
-        const u64 bs = (u64) __double_as_longlong(S);
+        const u64 bs = (u64) __double_as_longlong(sS);
         const int E = (int) ((bs >> 52) & 0x7FF);
-        sSerial = (E == 0 || E == 0x7FF || S < 0.0) ? 1 : 0;   // zero / subnormal / inf / nan: no binade to work in
+        sSerial = (E == 0 || (bs >> 63)) ? 1 : (E == 0x7FF ? 2 : 0);   // 1: no binade yet (S = 0), 2: inf/nan absorbs everything
         sK = E - 1023;
       }
       __syncthreads();
-      bool serial = sSerial != 0;
-      const int k = sK;
-      if (!serial && k != kLut) {                              // block-uniform: rebuild the increment table for this binade
+      const int mode = sSerial, k = sK;
+      if (mode == 2) { cb = hi; __syncthreads(); continue; }          // inf + x = inf
+      if (mode == 0 && k != kLut) {
         for (u32 v = t; v < RATIO_LUT; v += RATIO_THREADS) lut[v] = ratio_inc(v, k);
         kLut = k;
         __syncthreads();
       }
-      u64 acc = 0;
-      u32 bad = 0;
-      if (!serial) {
+      const u64 CAP = 1ull << 54;                                       // saturating sums: only "< 2^53" matters
+      u64 pre[RATIO_PER_THREAD];
+      u64 mine = 0;
+      u32 firstBad = 0xFFFFFFFFu;                                       // first term of mine that needs the serial add
+      const u32 e0 = t * RATIO_PER_THREAD;
+      if (mode == 0) {
         u32 nhv[RATIO_PER_THREAD];
 #pragma unroll
-        for (int r = 0; r < RATIO_PER_THREAD; ++r) {             // all loads of the chunk are in flight together
-          const u32 i = (u32) r * RATIO_THREADS + t;
-          nhv[r] = (i < cn) ? svals[cb + i] : 0xFFFFFFFFu;
+        for (int r = 0; r < RATIO_PER_THREAD; r += 4) {
+          if (e0 + r + 3 < cn) { const uint4 q = *(const uint4 *) (svals + cb + e0 + r); nhv[r] = q.x; nhv[r + 1] = q.y; nhv[r + 2] = q.z; nhv[r + 3] = q.w; }
+          else { for (int z = 0; z < 4; ++z) nhv[r + z] = (e0 + r + z < cn) ? svals[cb + e0 + r + z] : 0xFFFFFFFFu; }
         }
 #pragma unroll
         for (int r = 0; r < RATIO_PER_THREAD; ++r) {
-          const u32 i = (u32) r * RATIO_THREADS + t;
-          if (i < cn) {
+          u64 inc = 0;
+          if (e0 + r < cn) {
             const u32 nh = nhv[r];
-            const u64 inc = (nh < RATIO_LUT) ? lut[nh] : ratio_inc(nh, k);
-            if (inc == RATIO_SENTINEL) bad = 1; else acc += inc;   // inc < 2^52: 64 lanes x 16 terms stay below 2^63
+            inc = (nh < RATIO_LUT) ? lut[nh] : ratio_inc(nh, k);
+            if (inc == RATIO_SENTINEL) { if (firstBad == 0xFFFFFFFFu) firstBad = e0 + r; inc = 0; }
           }
-        }
-        for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off); bad |= __shfl_down(bad, off); }
-        if (lane == 0) { wsum[w] = acc; wflag[w] = bad; }
-        __syncthreads();
-        if (t == 0) {
-          u64 tot = 0; u32 anybad = 0;
-          for (u32 q = 0; q < RATIO_THREADS / 64; ++q) {          // overflow-safe: a wave sum >= 2^53 already means "leaves the binade"
-            if (wsum[q] >= (1ull << 53)) anybad = 1; else tot += wsum[q];
-            anybad |= wflag[q];
-          }
-          const u64 N = ((u64) __double_as_longlong(sS) & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-          if (anybad || tot >= (1ull << 53) || N + tot >= (1ull << 53)) sSerial = 1;   // would leave the binade (or needs N's parity)
-          else {
-            const u64 N2 = N + tot;                             // still in [2^52, 2^53): same exponent, new mantissa
-            sS = __longlong_as_double((long long) ((((u64) (sK + 1023)) << 52) | (N2 & 0xFFFFFFFFFFFFFull)));
-          }
-        }
-        __syncthreads();
-        serial = sSerial != 0;
-      }
-      if (serial) {
-        cn = min(cn, (u32) RATIO_SERIAL_STEP);
-        if (t == 0) {                                           // the reference's own loop, one add at a time
-          double S = sS;
-          for (u32 i = 0; i < cn; ++i) S = __dadd_rn(S, __ddiv_rn(1.0, (double) svals[cb + i]));
-          sS = S;
+          mine = min(mine + inc, CAP);
+          pre[r] = mine;                                                // inclusive prefix inside my 16 terms
         }
       }
-      cb += cn;
+      // block exclusive scan of the thread totals (saturating)
+      u64 x = mine;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u64 y = __shfl_up(x, off);
+        if ((int) lane >= off) x = min(x + y, CAP);
+      }
+      if (lane == 63) wsum[w] = x;
+      __syncthreads();
+      u64 base = x - mine;                                              // exact: x < CAP unless saturated, then base >= 2^53 anyway
+      if (x >= CAP) base = CAP;
+      for (u32 q = 0; q < w; ++q) base = min(base + wsum[q], CAP);
+      // my first term that cannot be an integer step
+      const u64 N0 = ((u64) __double_as_longlong(sS) & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+      u32 stopAt = 0xFFFFFFFFu;
+      if (mode == 1) { if (t == 0) stopAt = 0; }
+      else {
+#pragma unroll
+        for (int r = 0; r < RATIO_PER_THREAD; ++r) {
+          if (stopAt == 0xFFFFFFFFu && e0 + r < cn) {
+            const bool cross = min(N0 + min(base + pre[r], CAP), CAP) >= (1ull << 53);
+            if (cross || firstBad == e0 + r) stopAt = e0 + r;
+          }
+        }
+      }
+      u32 m = stopAt;
+      for (int off = 32; off > 0; off >>= 1) m = min(m, (u32) __shfl_down(m, off));
+      if (lane == 0) wflag[w] = m;
+      __syncthreads();
+      u32 stop = 0xFFFFFFFFu;
+      for (u32 q = 0; q < RATIO_THREADS / 64; ++q) stop = min(stop, wflag[q]);
+      // the owner of the stop term publishes the increment sum of everything before it
+      if (stop != 0xFFFFFFFFu) {
+        if (stop >= e0 && stop < e0 + RATIO_PER_THREAD) {
+          const u32 r = stop - e0;
+          u64 before = base;
+#pragma unroll
+          for (int z = 0; z < RATIO_PER_THREAD; ++z) if ((u32) z + 1 == r) before = base + pre[z];
+          sBefore = (mode == 1) ? 0 : before;
+        }
+      } else if (t == RATIO_THREADS - 1) sBefore = min(base + mine, CAP);   // whole chunk applies
+      __syncthreads();
+      if (t == 0) {
+        double S = sS;
+        if (mode == 0) {
+          const u64 N2 = N0 + sBefore;                                  // < 2^53 by construction
+          S = __longlong_as_double((long long) ((((u64) (k + 1023)) << 52) | (N2 & 0xFFFFFFFFFFFFFull)));
+        }
+        if (stop != 0xFFFFFFFFu) S = __dadd_rn(S, __ddiv_rn(1.0, (double) svals[cb + stop]));   // the reference's own add
+        sS = S;
+      }
+      cb += (stop != 0xFFFFFFFFu) ? stop + 1 : cn;
       __syncthreads();
     }
     if (t == 0) G.sum[slot] = sS;
@@ -1130,6 +1252,8 @@ struct mm_ctx {
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
+  u64 *d_tileTot = nullptr;
+  int *d_tileK = nullptr;
   size_t last_n = 0;
   const int4 *last_aln = nullptr;   // device tuples of the last batch (valid until the next mm_annotate_batch)
   // persistent state
@@ -1378,7 +1502,8 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 static void ctx_free_batch(mm_ctx *c) {
   (void) hipFree(c->d_aln); (void) hipFree(c->d_nh); (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
-  (void) hipFree(c->d_hist); (void) hipFree(c->d_tile);
+  (void) hipFree(c->d_hist); (void) hipFree(c->d_tile); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
+  c->d_tileTot = nullptr; c->d_tileK = nullptr;
   c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
   c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr; c->d_tile = nullptr;
   c->cap = 0;
@@ -1445,6 +1570,7 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4)); HIPCHK(hipMalloc((void **) &c->d_tile, (nblk + 1) * 4));
+    HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
   if (need_copy && !c->d_aln) {
@@ -1569,7 +1695,8 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     else {  // 16 key bits = two passes: the sorted pairs are back in A
       HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
       hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_M, c->d_seg, c->d_seg + GT_CAP);
-      hipLaunchKernelGGL(k_ratio_rows, dim3(512), dim3(RATIO_THREADS), 0, c->stream, c->d_vA, c->d_seg, c->d_seg + GT_CAP, c->G);
+      hipLaunchKernelGGL(k_ratio_tiles, dim3((u32) (n / RATIO_CHUNK + 1)), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_M, c->G, c->d_tileTot, c->d_tileK);
+      hipLaunchKernelGGL(k_ratio_rows, dim3(GT_CAP / RATIO_SLOTS_PER_WG), dim3(RATIO_THREADS), 0, c->stream, c->d_vA, c->d_seg, c->d_seg + GT_CAP, c->G, c->d_tileTot, c->d_tileK);
     }
     HIPCHK(hipGetLastError());
   }
