@@ -1247,8 +1247,15 @@ struct mm_ctx {
   bool finalized = false;
   // batch buffers
   size_t cap = 0;
-  int4 *d_aln = nullptr;
+  int4 *d_aln = nullptr;   // = d_alnBuf[cur]
   u32 *d_nh = nullptr;
+  // host-tuple path: two staging sets filled by a dedicated copy stream, so the copy of batch k+1 overlaps the kernels of batch k
+  int4 *d_alnBuf[2] = {nullptr, nullptr};
+  u32 *d_nhBuf[2] = {nullptr, nullptr};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool consumed_valid[2] = {false, false};
+  int cur = 0;
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
@@ -1270,11 +1277,13 @@ struct mm_ctx {
 
 struct PhaseTimer {  // records an event pair around a group of launches when profiling is on
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t stream_override = nullptr;
   PhaseTimer(mm_ctx *c_, int ph) : c(c_), phase(ph) {
     if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void) hipEventRecord(a, c->stream);
   }
+  void restart() { if (a) (void) hipEventRecord(a, stream_override ? stream_override : c->stream); }
   void stop() {
-    if (a && b) { (void) hipEventRecord(b, c->stream); c->spans.push_back({phase, a, b}); a = b = nullptr; }
+    if (a && b) { (void) hipEventRecord(b, stream_override ? stream_override : c->stream); c->spans.push_back({phase, a, b}); a = b = nullptr; }
   }
   ~PhaseTimer() { stop(); }
 };
@@ -1500,7 +1509,8 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 }
 
 static void ctx_free_batch(mm_ctx *c) {
-  (void) hipFree(c->d_aln); (void) hipFree(c->d_nh); (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
+  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); (void) hipFree(c->d_nhBuf[b]); c->d_alnBuf[b] = nullptr; c->d_nhBuf[b] = nullptr; c->consumed_valid[b] = false; }
+  (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tile); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
   c->d_tileTot = nullptr; c->d_tileK = nullptr;
@@ -1541,6 +1551,11 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
+  if (c->copy_stream) {
+    (void) hipStreamSynchronize(c->copy_stream);
+    for (int b = 0; b < 2; ++b) { (void) hipEventDestroy(c->ev_copied[b]); (void) hipEventDestroy(c->ev_consumed[b]); }
+    (void) hipStreamDestroy(c->copy_stream);
+  }
   if (c->own_stream) (void) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1560,8 +1575,9 @@ extern "C" int mm_reset(mm_ctx *c) {
 }
 
 static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
-  if (n <= c->cap && (!need_copy || c->d_aln)) return MM_OK;
+  if (n <= c->cap && (!need_copy || c->d_alnBuf[0])) return MM_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
   size_t cap = std::max<size_t>(n, 1 << 16);
   if (n > c->cap) {
     ctx_free_batch(c);
@@ -1573,9 +1589,14 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
-  if (need_copy && !c->d_aln) {
-    HIPCHK(hipMalloc((void **) &c->d_aln, c->cap * sizeof(int4))); HIPCHK(hipMalloc((void **) &c->d_nh, c->cap * 4));
+  if (need_copy && !c->d_alnBuf[0]) {
+    for (int b = 0; b < 2; ++b) { HIPCHK(hipMalloc((void **) &c->d_alnBuf[b], c->cap * sizeof(int4))); HIPCHK(hipMalloc((void **) &c->d_nhBuf[b], c->cap * 4)); }
+    if (!c->copy_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      for (int b = 0; b < 2; ++b) { HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_consumed[b], hipEventDisableTiming)); }
+    }
   }
+  c->d_aln = c->d_alnBuf[0]; c->d_nh = c->d_nhBuf[0];
   return MM_OK;
 }
 
@@ -1653,10 +1674,22 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
   if (dflt && nh) { rc = ensure_qids(c, qid_bound ? qid_bound : 1); if (rc) return rc; }
   const int4 *d_aln = (const int4 *) aln;
   const u32 *d_nh = nh;
+  int staged = -1;
   if (!on_device) {
-    PhaseTimer t(c, MM_PHASE_H2D);
-    HIPCHK(hipMemcpyAsync(c->d_aln, aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->stream));
-    if (nh) HIPCHK(hipMemcpyAsync(c->d_nh, nh, n * 4, hipMemcpyHostToDevice, c->stream));
+    // copy stream: wait until the kernels that last read this staging set are done, copy, signal; the compute stream
+    // waits for the signal.  With two sets the copy of this batch overlaps the kernels of the previous one.
+    const int b = c->cur; c->cur ^= 1; staged = b;
+    if (c->consumed_valid[b]) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[b], 0));
+    {
+      PhaseTimer t(c, MM_PHASE_H2D);
+      t.stream_override = c->copy_stream;
+      t.restart();
+      HIPCHK(hipMemcpyAsync(c->d_alnBuf[b], aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->copy_stream));
+      if (nh) HIPCHK(hipMemcpyAsync(c->d_nhBuf[b], nh, n * 4, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+    c->d_aln = c->d_alnBuf[b]; c->d_nh = c->d_nhBuf[b];
     d_aln = c->d_aln; d_nh = nh ? c->d_nh : nullptr;
   }
   ProbeParams P;
@@ -1700,6 +1733,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     }
     HIPCHK(hipGetLastError());
   }
+  if (staged >= 0) { HIPCHK(hipEventRecord(c->ev_consumed[staged], c->stream)); c->consumed_valid[staged] = true; }
   return MM_OK;
 }
 
