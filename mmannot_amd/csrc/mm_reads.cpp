@@ -11,7 +11,11 @@
 // given verbatim run did (every record '+', or every record '-').
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -35,33 +39,178 @@ struct AltHit {
   std::vector<CigarOp> cigar;
 };
 
-struct ByteSource {  // sequential reader over gzread (plain gzip, BGZF and uncompressed input alike)
+// BGZF (the blocked gzip of real BAM files): every block is an independent gzip member of <= 64 KiB with its
+// compressed size in a 'BC' extra field, so blocks can be inflated in parallel.  A producer thread reads a batch of
+// blocks, inflates them with a few helper threads straight into one contiguous buffer, and hands the buffer over
+// while the consumer is still parsing the previous one (two buffers).
+struct BgzfPipe {
+  FILE *f = nullptr;
+  int n_threads = 4;
+  struct Batch { std::vector<uint8_t> data; size_t len = 0; bool last = false, bad = false; };
+  Batch slot[2];
+  int ready[2] = {0, 0};       // 0 = free for the producer, 1 = filled for the consumer
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread producer;
+  bool stop = false;
+  int take = 0;
+
+  static bool is_bgzf(const char *path) {
+    FILE *g = fopen(path, "rb");
+    if (!g) return false;
+    unsigned char h[18];
+    const bool ok = fread(h, 1, 18, g) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 &&
+                    h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    fclose(g);
+    return ok;
+  }
+  bool open(const char *path) {
+    f = fopen(path, "rb");
+    if (!f) return false;
+    n_threads = (int) std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    producer = std::thread([this] { run(); });
+    return true;
+  }
+  void run() {
+    const size_t BATCH_BLOCKS = 512;
+    std::vector<uint8_t> raw;
+    std::vector<size_t> coff, clen, uoff, ulen;
+    int put = 0;
+    bool eof = false;
+    while (!eof) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || ready[put] == 0; });
+        if (stop) return;
+      }
+      Batch &B = slot[put];
+      raw.clear(); coff.clear(); clen.clear(); uoff.clear(); ulen.clear();
+      size_t total = 0;
+      B.bad = false;
+      while (coff.size() < BATCH_BLOCKS) {
+        unsigned char h[18];
+        const size_t got = fread(h, 1, 18, f);
+        if (got == 0) { eof = true; break; }
+        if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') { B.bad = true; eof = true; break; }
+        const size_t bsize = (size_t) (h[16] | (h[17] << 8)) + 1;       // whole block
+        if (bsize < 26) { B.bad = true; eof = true; break; }
+        const size_t o = raw.size();
+        raw.resize(o + bsize);
+        memcpy(&raw[o], h, 18);
+        if (fread(&raw[o + 18], 1, bsize - 18, f) != bsize - 18) { B.bad = true; eof = true; break; }
+        uint32_t isize;
+        memcpy(&isize, &raw[o + bsize - 4], 4);
+        if (isize > 65536) { B.bad = true; eof = true; break; }
+        coff.push_back(o); clen.push_back(bsize); uoff.push_back(total); ulen.push_back(isize);
+        total += isize;
+      }
+      if (B.data.size() < total) B.data.resize(total);
+      B.len = total;
+      const size_t nb = coff.size();
+      std::vector<int> fail((size_t) n_threads, 0);
+      auto work = [&](int tid) {
+        z_stream z;
+        for (size_t i = (size_t) tid; i < nb; i += (size_t) n_threads) {
+          if (ulen[i] == 0) continue;
+          memset(&z, 0, sizeof z);
+          if (inflateInit2(&z, -15) != Z_OK) { fail[tid] = 1; return; }
+          z.next_in = &raw[coff[i] + 18]; z.avail_in = (uInt) (clen[i] - 26);
+          z.next_out = &B.data[uoff[i]]; z.avail_out = (uInt) ulen[i];
+          const int rc = inflate(&z, Z_FINISH);
+          inflateEnd(&z);
+          if (rc != Z_STREAM_END || z.avail_out != 0) { fail[tid] = 1; return; }
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+      for (int v : fail) if (v) B.bad = true;
+      B.last = eof;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ready[put] = 1;
+      }
+      cv.notify_all();
+      put ^= 1;
+    }
+  }
+  // next filled batch (nullptr at end); the previous one is released
+  Batch *next(bool release_prev) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (release_prev) { ready[take ^ 1] = 0; cv.notify_all(); }
+    cv.wait(lk, [&] { return ready[take] == 1; });
+    Batch *b = &slot[take];
+    take ^= 1;
+    return b;
+  }
+  void close() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (producer.joinable()) producer.join();
+    if (f) { fclose(f); f = nullptr; }
+  }
+};
+
+struct ByteSource {  // sequential reader: BGZF through BgzfPipe, anything else (plain gzip, uncompressed) through gzread
   gzFile f = nullptr;
+  BgzfPipe *pipe = nullptr;
+  BgzfPipe::Batch *cur = nullptr;
+  bool pipe_done = false;
   std::vector<uint8_t> buf;
+  const uint8_t *p = nullptr;
   size_t pos = 0, len = 0;
   bool eof = false;
+  std::string err;
   bool open(const char *path) {
+    if (BgzfPipe::is_bgzf(path)) {
+      pipe = new BgzfPipe();
+      if (!pipe->open(path)) { delete pipe; pipe = nullptr; return false; }
+      return true;
+    }
     f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
     buf.resize(4 << 20);
+    p = buf.data();
     return true;
   }
-  void close() { if (f) { gzclose(f); f = nullptr; } }
+  void close() {
+    if (f) { gzclose(f); f = nullptr; }
+    if (pipe) { pipe->close(); delete pipe; pipe = nullptr; }
+  }
   bool fill() {
     if (eof) return false;
+    if (pipe) {
+      for (;;) {
+        if (pipe_done) { eof = true; len = pos = 0; return false; }
+        cur = pipe->next(cur != nullptr);
+        if (cur->bad) { err = "corrupt BGZF block"; eof = true; len = pos = 0; return false; }
+        if (cur->last) pipe_done = true;
+        if (cur->len) { p = cur->data.data(); len = cur->len; pos = 0; return true; }
+      }
+    }
     const int n = gzread(f, buf.data(), (unsigned) buf.size());
     if (n <= 0) { eof = true; len = pos = 0; return false; }
+    p = buf.data();
     len = (size_t) n; pos = 0;
     return true;
   }
   // false when fewer than n bytes remain
-  bool read(void *dst, size_t n) {
+  inline bool read(void *dst, size_t n) {
+    if (len - pos >= n) {                       // fast path: inside the current buffer
+      if (dst) memcpy(dst, p + pos, n);
+      pos += n;
+      return true;
+    }
     uint8_t *d = (uint8_t *) dst;
     while (n) {
       if (pos == len && !fill()) return false;
       const size_t k = std::min(n, len - pos);
-      if (d) { memcpy(d, buf.data() + pos, k); d += k; }
+      if (d) { memcpy(d, p + pos, k); d += k; }
       pos += k; n -= k;
     }
     return true;
@@ -69,7 +218,61 @@ struct ByteSource {  // sequential reader over gzread (plain gzip, BGZF and unco
   bool skip(size_t n) { return read(nullptr, n); }
   int getc() {
     if (pos == len && !fill()) return -1;
-    return buf[pos++];
+    return p[pos++];
+  }
+};
+
+}  // namespace
+
+namespace {
+
+// Read-name dictionary: name -> dense id in first-appearance order (the reference keys its maps on the name string,
+// mmannot.cpp:1656-1662).  Open addressing over an arena of the names; no allocation per record.
+struct NameDict {
+  std::vector<char> arena;            // names back to back, each NUL-terminated
+  std::vector<uint64_t> name_off;     // id -> offset in arena
+  std::vector<uint32_t> table;        // slot -> id + 1 (0 = empty)
+  std::vector<uint32_t> hashes;       // id -> 32-bit hash (cheap pre-compare, reused when growing)
+  size_t mask = 0;
+  static uint64_t hash(const char *p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; p += 8; n -= 8; }
+    uint64_t w = 0; memcpy(&w, p, n);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+    return h;
+  }
+  void grow() {
+    const size_t cap = table.empty() ? (1u << 16) : table.size() * 2;
+    table.assign(cap, 0); mask = cap - 1;
+    for (uint32_t id = 0; id < name_off.size(); ++id) {
+      size_t s = hashes[id] & mask;
+      while (table[s]) s = (s + 1) & mask;
+      table[s] = id + 1;
+    }
+  }
+  uint32_t size() const { return (uint32_t) name_off.size(); }
+  const char *name(uint32_t id) const { return id < name_off.size() ? arena.data() + name_off[id] : ""; }
+  uint32_t get(const char *p, size_t n) {
+    if ((name_off.size() + 1) * 2 > table.size()) grow();
+    const uint32_t h = (uint32_t) hash(p, n);
+    size_t s = h & mask;
+    for (;;) {
+      const uint32_t e = table[s];
+      if (!e) break;
+      const uint32_t id = e - 1;
+      if (hashes[id] == h) {
+        const char *q = arena.data() + name_off[id];
+        if (strncmp(q, p, n) == 0 && q[n] == 0) return id;
+      }
+      s = (s + 1) & mask;
+    }
+    const uint32_t id = (uint32_t) name_off.size();
+    name_off.push_back(arena.size());
+    arena.insert(arena.end(), p, p + n);
+    arena.push_back('\0');
+    hashes.push_back(h);
+    table[s] = id + 1;
+    return id;
   }
 };
 
@@ -96,9 +299,12 @@ struct mm_reader {
   bool have_record = false;
   bool over = false;
   // dictionaries
-  std::unordered_map<std::string, uint32_t> qids;
-  std::vector<std::string> names;
+  NameDict qids;
   std::unordered_map<std::string, int32_t> chr_tid;  // read chromosome name -> annotation chromosome id (-1 unknown)
+  std::vector<int32_t> bam_tid;                      // BAM reference id -> annotation chromosome id (-2 = not resolved yet)
+  int32_t cur_ref = -2;                              // reference id of the current BAM record (-2: use the name)
+  char name_buf[512];
+  size_t name_len = 0;
   std::vector<std::string> unknown_warned;
   uint64_t n_reads = 0;
   uint64_t cur_end = 0;   // Read::end of the read delivered last (a '*' CIGAR of an alternative keeps it)
@@ -172,6 +378,8 @@ static bool next_sam_record(mm_reader *r) {
     r->chromosome = col[2];
     r->rec_start = std::stoul(col[3]);
     r->name = col[0];
+    r->name_len = std::min(col[0].size(), sizeof(r->name_buf) - 1); memcpy(r->name_buf, col[0].data(), r->name_len); r->name_buf[r->name_len] = 0;
+    r->cur_ref = -2;
     r->nhits = 1;
     parse_cigar_text(col[5], r->cigar);
     for (size_t i = 11; i < col.size(); ++i) {
@@ -201,16 +409,16 @@ static bool next_bam_record(mm_reader *r) {
   uint32_t bin_mq_nl, flag_nc;
   r->cigar.clear(); r->alts.clear();
   if (!s.read(&chr_id, 4) || !s.read(&pos, 4) || !s.read(&bin_mq_nl, 4) || !s.read(&flag_nc, 4) || !s.read(&l_seq, 4) || !s.skip(12)) return false;
-  if (chr_id == -1) r->chromosome = "*";
-  else if (chr_id >= 0 && (size_t) chr_id < r->bam_chr.size()) r->chromosome = r->bam_chr[chr_id];
+  if (chr_id == -1) r->cur_ref = (int32_t) r->bam_chr.size() - 1;      // the "*" entry appended behind the header's names
+  else if (chr_id >= 0 && (size_t) chr_id + 1 < r->bam_chr.size()) r->cur_ref = chr_id;
   else { r->err = "BAM record refers to reference sequence " + std::to_string(chr_id) + " which the header does not declare"; return false; }
   r->rec_start = (uint64_t) (int64_t) (pos + 1);
   const int32_t l_name = (int32_t) (bin_mq_nl & 0xff), n_cigar = (int32_t) (flag_nc & 0xffff);
   const uint32_t flags = flag_nc >> 16;
   r->rec_strand = (flags & 0x10) == 0;
-  std::string nm((size_t) l_name, '\0');
-  if (l_name && !s.read(&nm[0], (size_t) l_name)) return false;
-  r->name = std::string(nm.c_str());
+  if (l_name && !s.read(r->name_buf, (size_t) l_name)) return false;   // l_read_name is one byte: at most 255
+  r->name_buf[l_name] = 0;
+  r->name_len = strlen(r->name_buf);
   static const char OPS[] = "MIDNSHP=X";
   for (int32_t i = 0; i < n_cigar; ++i) {
     uint32_t v;
@@ -330,6 +538,8 @@ extern "C" int mm_reader_open(mm_reader **out, const char *path, int format, con
       r->bam_chr.push_back(std::string(nm.c_str()));
       r->src.skip(4);
     }
+    r->bam_chr.push_back("*");
+    r->bam_tid.assign(r->bam_chr.size(), -2);
   } else {
     r->log += "Reading SAM file " + r->path + "\n";
     r->sam.open(path);
@@ -346,16 +556,18 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
   uint64_t &cur_end = r->cur_end;
   while (n < cap && !r->over) {
     std::string chr;
-    bool strand;
+    bool strand, is_alt = false;
     uint64_t start, end;
     if (r->have_record && r->alt_next < r->alts.size()) {
       const AltHit &ah = r->alts[r->alt_next++];
+      is_alt = true;
       chr = ah.chromosome; strand = ah.strand; start = ah.start;
       end = cigar_end(ah.cigar, start, cur_end, r->log);
     } else {
       const bool ok = r->is_bam ? next_bam_record(r) : next_sam_record(r);
       if (!ok) {
         r->over = true;
+        if (r->err.empty() && !r->src.err.empty()) r->err = r->src.err + " in '" + r->path + "'";
         if (!r->err.empty()) { r->have_record = false; *n_out = n; return MM_ERR_PARSE; }
         // At end of file the reference calls read.reset() once more on the stale last record (mmannot.cpp:1414-1415,
         // 1444-1447, 1527-1532): its CIGAR is parsed again and any complaint about it is printed a second time.
@@ -364,23 +576,21 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
         break;
       }
       r->have_record = true; r->alt_next = 0;
-      chr = r->chromosome; start = r->rec_start;
+      start = r->rec_start;
       strand = (r->strand_compat == MM_STRAND_COMPAT_PLUS) ? true : (r->strand_compat == MM_STRAND_COMPAT_MINUS ? false : r->rec_strand);
       end = cigar_end(r->cigar, start, start, r->log);
     }
     cur_end = end;
     if (start > 0x7FFFFFF0ull || (end > 0x7FFFFFF0ull && end != start - 1)) {
-      r->err = "alignment coordinate outside the supported range [0, 2^31) for read " + r->name; *n_out = n; return MM_ERR_RANGE;
+      r->err = std::string("alignment coordinate outside the supported range [0, 2^31) for read ") + r->name_buf; *n_out = n; return MM_ERR_RANGE;
     }
     const bool reaches_scan = !r->unique_only || r->nhits == 1;   // mmannot.cpp:1773
-    const int32_t tid = tid_of(r, chr, reaches_scan);
-    auto it = r->qids.find(r->name);
-    uint32_t q;
-    if (it == r->qids.end()) {
-      q = (uint32_t) r->qids.size();
-      r->qids.emplace(r->name, q);
-      if (r->keep_names) r->names.push_back(r->name);
-    } else q = it->second;
+    int32_t tid;
+    if (!is_alt && r->is_bam && r->cur_ref >= 0) {                // primary BAM record: chromosome known by reference id
+      tid = r->bam_tid[r->cur_ref];
+      if (tid == -2 || (tid < 0 && reaches_scan)) { tid = tid_of(r, r->bam_chr[r->cur_ref], reaches_scan); r->bam_tid[r->cur_ref] = tid; }
+    } else tid = tid_of(r, is_alt ? chr : r->chromosome, reaches_scan);
+    const uint32_t q = r->qids.get(r->name_buf, r->name_len);
     aln[n].start = (int32_t) start;
     aln[n].end = (int32_t) (int64_t) end;
     aln[n].tid_strand = MM_ALN_TID_STRAND(tid, strand);
@@ -395,7 +605,7 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
 extern "C" uint64_t mm_reader_qid_bound(const mm_reader *r) { return r ? (uint64_t) r->qids.size() : 0; }
 extern "C" uint64_t mm_reader_n_reads(const mm_reader *r) { return r ? r->n_reads : 0; }
 extern "C" const char *mm_reader_name(const mm_reader *r, uint32_t qid) {
-  return (r && qid < r->names.size()) ? r->names[qid].c_str() : "";
+  return r ? r->qids.name(qid) : "";
 }
 // messages produced since the previous call, in the order the reference would have written them to stderr
 extern "C" const char *mm_reader_take_log(mm_reader *r) {

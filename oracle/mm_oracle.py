@@ -377,6 +377,30 @@ def write_bam_bytes(path: str, chroms: Sequence[Tuple[str, int]], body: bytes, l
         f.write(co.flush())
 
 
+def write_bgzf(path: str, payload: bytes, level: int = 1, block: int = 0xff00) -> None:
+    """BGZF container (the blocked gzip real BAM files use): independent <= 64 KiB gzip members with a 'BC' extra field
+    holding the compressed block size, plus the empty end-of-file block."""
+    import zlib
+    with open(path, "wb") as f:
+        def member(chunk: bytes):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = co.compress(chunk) + co.flush()
+            bsize = len(comp) + 25                      # total block size - 1
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+                    struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        for o in range(0, len(payload), block):
+            member(payload[o:o + block])
+        member(b"")
+
+
+def write_bam_bgzf(path: str, chroms: Sequence[Tuple[str, int]], body: bytes, level: int = 1) -> None:
+    hdr = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", len(chroms))
+    for nm, ln in chroms:
+        b = nm.encode() + b"\0"
+        hdr += struct.pack("<i", len(b)) + b + struct.pack("<i", ln)
+    write_bgzf(path, hdr + body, level)
+
+
 def names_to_qid(names: Sequence[str]) -> np.ndarray:
     d: Dict[str, int] = {}
     out = np.empty(len(names), dtype=np.int64)

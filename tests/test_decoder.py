@@ -1,0 +1,59 @@
+"""CPU (host logic): the reads decoder on BGZF input (parallel block inflation, mm_reads.cpp:BgzfPipe) must produce exactly the
+tuples it produces for the same BAM stored as one plain gzip member (the gzread path, which test_kat / test_synth_e2e pin
+against the compiled reference)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import synth_ref as sr
+
+
+def _bam_payload(path):
+    return gzip.open(path, "rb").read()
+
+
+@pytest.mark.parametrize("block", [97, 4096, 0xff00])
+def test_bgzf_equals_gzip(oracle, tmp_path, block):
+    import mmannot_amd.api as api
+    # a KAT with XA / NM / Z tags and a synthetic stream
+    kat = os.path.join(gu.GOLD, "kat", "X1_xa")
+    an = api.Annotation(os.path.join(kat, "c.cfg"), os.path.join(kat, "a.gtf"))
+    src = os.path.join(kat, "r.bam")
+    b = tmp_path / "x.bam"
+    oracle.write_bgzf(str(b), _bam_payload(src), level=6, block=block)
+    a0, h0 = api.ReadsDecoder(src, an).read_all()
+    a1, h1 = api.ReadsDecoder(str(b), an).read_all(cap=2)
+    assert (a0 == a1).all() and (h0 == h1).all() and len(a0) == 7
+
+    rng = np.random.default_rng(3)
+    n = 50000
+    chroms = [("chr1", 100000), ("chrZ", 50000)]
+    body = oracle.bam_records_fixed(rng.integers(-1, 2, n), rng.integers(0, 90000, n), rng.integers(0, 32, n).astype(np.uint16) & 16,
+                                    rng.integers(0, 9000, n), rng.integers(20, 150, n), rng.integers(0, 9, n).astype(np.uint32))
+    p0, p1 = tmp_path / "g.bam", tmp_path / "b.bam"
+    oracle.write_bam_bytes(str(p0), chroms, body, level=1)
+    oracle.write_bam_bgzf(str(p1), chroms, body, level=1)
+    if block != 0xff00:
+        oracle.write_bgzf(str(p1), _bam_payload(str(p0)), level=1, block=block * 13)
+    d0, d1 = api.ReadsDecoder(str(p0), an), api.ReadsDecoder(str(p1), an)
+    x0, y0 = d0.read_all()
+    x1, y1 = d1.read_all(cap=777)
+    assert len(x0) == n and (x0 == x1).all() and (y0 == y1).all()
+    assert d0.take_log() .replace(str(p0), "F") == d1.take_log().replace(str(p1), "F")
+    assert d0.qid_bound() == d1.qid_bound() and d0.name(5) == d1.name(5)
+
+
+def test_truncated_bgzf_is_an_error(oracle, tmp_path):
+    import mmannot_amd.api as api
+    from mmannot_amd import MMError
+    kat = os.path.join(gu.GOLD, "kat", "E1_overcomplete")
+    an = api.Annotation(os.path.join(kat, "c.cfg"), os.path.join(kat, "a.gtf"))
+    b = tmp_path / "t.bam"
+    oracle.write_bgzf(str(b), _bam_payload(os.path.join(kat, "r.bam")), level=6, block=64)
+    raw = open(b, "rb").read()
+    open(b, "wb").write(raw[:len(raw) // 2 + 3])
+    with pytest.raises(MMError):
+        api.ReadsDecoder(str(b), an).read_all()
