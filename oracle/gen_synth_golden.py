@@ -67,6 +67,13 @@ def main():
             cases.append(dict(args=run, rc=rc, table=open(tsv).read(), stderr=se.replace(d, "$D"),
                               mfile=open(mf).read() if "$M" in run else None, mmfile=open(mmf).read() if "$MM" in run else None))
             print("synth_e2e", name, run, rc, cases[-1]["table"].count("\n") - 1, "rows", file=sys.stderr)
+        # two input files -> two columns (TableCount::addCounter), custom sample names (-n), stdout instead of -o
+        if name == "tair10":
+            w2 = dict(w, rseed=w["rseed"] + 100, n=w["n"] // 2)
+            d2 = tempfile.mkdtemp(prefix="mmsynth2")
+            _, _, bam2 = make_inputs(w2, d2)
+            rc, so, se = mo.run_ref("mmannot_patched", ["-a", gtf, "-c", cfg, "-s", "F", "-r", bam, bam2, "-n", "first", "second"])
+            out[name + "_two_files"] = dict(workload=w, workload2=w2, rc=rc, stdout=so, stderr=se.replace(d, "$D").replace(d2, "$E"))
         out[name] = dict(workload=w, cases=cases)
     json.dump(out, open(os.path.join(GOLD, "cases.json"), "w"), indent=1)
 
