@@ -4,7 +4,7 @@
 //   IntervalList::scan            :1291-1332   -> k_probe (candidate enumeration + strand + -l filter)
 //   EvaluationStructure::getFirst :1029-1076   -> priority selection inside k_probe
 //   Counter::addCount             :1665-1739   -> k_probe (per-hit branch), k_chunk_default (multi-hit
-//                                                 countdown / union), k_ratio_accum (-y ratio)
+//                                                 countdown / union), k_ratio_tiles + k_ratio_rows (-y ratio)
 //   Counter::read flush           :1783-1792   -> k_flush_pending
 //   Counter::getCounts / dump     :1803-1818   -> mm_get_rows / mm_get_stats
 //
@@ -740,9 +740,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
 __global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ kA, const u32 *__restrict__ vA, const u32 *__restrict__ kB,
                                                        const u32 *__restrict__ vB, const u32 *__restrict__ info,
                                                        const u32 *__restrict__ nhp, const u64 *__restrict__ hm, u32 *__restrict__ grpRem,
-                                                       u64 *__restrict__ grpU, GlobalTable G, u64 *__restrict__ stats) {
+                                                       u64 *__restrict__ grpU, u64 qcap, GlobalTable G, u64 *__restrict__ stats) {
   __shared__ LdsTable T;
   __shared__ u32 sOpened, sRescued;
+  // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
+  if (info[INFO_M] != 0 && (u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicExch(G.err, 2u); return; }
   lds_table_init(T);
   if (threadIdx.x == 0) { sOpened = 0; sRescued = 0; }
   __syncthreads();
@@ -1258,7 +1260,7 @@ struct mm_ctx {
   int cur = 0;
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
-  u32 *d_hist = nullptr, *d_tile = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
+  u32 *d_hist = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
   u64 *d_tileTot = nullptr;
   int *d_tileK = nullptr;
   size_t last_n = 0;
@@ -1512,10 +1514,10 @@ static void ctx_free_batch(mm_ctx *c) {
   for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); (void) hipFree(c->d_nhBuf[b]); c->d_alnBuf[b] = nullptr; c->d_nhBuf[b] = nullptr; c->consumed_valid[b] = false; }
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
-  (void) hipFree(c->d_hist); (void) hipFree(c->d_tile); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
+  (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
   c->d_tileTot = nullptr; c->d_tileK = nullptr;
   c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
-  c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr; c->d_tile = nullptr;
+  c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr;
   c->cap = 0;
 }
 
@@ -1585,7 +1587,7 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_gpay, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
-    HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4)); HIPCHK(hipMalloc((void **) &c->d_tile, (nblk + 1) * 4));
+    HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4));
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
@@ -1724,7 +1726,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     PhaseTimer t(c, MM_PHASE_MERGE);
     if (dflt)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
-                         c->d_grpRem, c->d_grpU, c->G, c->d_stats);
+                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
     else {  // 16 key bits = two passes: the sorted pairs are back in A
       HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
       hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_M, c->d_seg, c->d_seg + GT_CAP);
@@ -1741,6 +1743,7 @@ static int check_table(mm_ctx *c) {
   u32 err = 0;
   HIPCHK(hipMemcpyAsync(&err, c->G.err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (err == 2) return fail(MM_ERR_ARG, "a read-name id (qid) of the batch is not below the qid_bound given to mm_annotate_batch; the batch's multi-hit records were not merged");
   if (err) return fail(MM_ERR_TABLE_FULL, "more than 65536 distinct element sets");
   return MM_OK;
 }

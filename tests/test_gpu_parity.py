@@ -172,3 +172,18 @@ def test_ratio_large_stream(gpu_lib, oracle, nh_max, strand, l):
     assert got == want
     assert max(ref.row_sum) > (1e4 if nh_max > 3 else 1e5)   # rows large enough to leave the serial warm-up
     ctr.close(); index.close()
+
+
+def test_qid_bound_too_small_is_an_error_not_a_fault(gpu_lib):
+    mm = gpu_lib
+    rng = np.random.default_rng(1)
+    desc = sr.random_config(rng, 3, 1)
+    ix = sr.random_index(rng, desc.E, nchr=1, n=20, maxpos=20000)
+    index = mm.IntervalIndex(to_cfg(mm, desc), ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], 1)
+    ctr = mm.Counter(index)
+    n = 1000
+    aln = mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n) + 5_000_000)   # ids far beyond the bound
+    ctr.add_batch(aln, np.full(n, 2, dtype=np.uint32), 10)
+    with pytest.raises(mm.MMError):
+        ctr.sync()
+    ctr.close(); index.close()
