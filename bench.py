@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--batch-log2", type=int, default=24)
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--bin-shift", type=int, default=0, help="log2 of the index bin width (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--from-host", action="store_true", help="informational: tuples start in pinned host memory (PCIe-inclusive rate, never `value` of record)")
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
@@ -76,7 +77,7 @@ def main():
         wname = "c2: synthetic 50bp SE reads, NH=1, TAIR10-scale annotation, -y default -s F -l -1"
     strategy = "ratio" if args.workload == "c5" else "default"
     cfg = mm.Config.from_json(an.config)
-    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank)
+    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank, bin_shift=args.bin_shift)
     info = index.info()
     stream = torch.cuda.current_stream().cuda_stream
     ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy, stream=stream)

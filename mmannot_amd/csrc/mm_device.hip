@@ -319,14 +319,49 @@ __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, i
   return ok && ((float) ov >= P.overlapValue);
 }
 
-template <int OVL>
-__device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c, int s, int e, int rstrand, u32 t, u32 &o_out, u32 &d_out);
+// The slot walk, written once as a statement macro and expanded with two visitors (plain straight-line code: callbacks made
+// the compiler keep closures and a copy of the parameter block in scratch).  VISIT(rx, ry) sees, in index order, every
+// record that can concern the read [s,e] (e >= s): the whole slot of the bin of s, then only the "starts here" part of
+// the following bins up to the bin of e.  The slot's first 32 bytes (header + 3 records) are requested first, the rest
+// of its first half and its second half only when the header says they hold records.
+#define MM_SLOT_WALK(VISIT)                                                                      \
+  for (u32 b_ = b0; b_ <= b1; ++b_) {                                                            \
+    const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 8;                                        \
+    const uint4 q0 = S_[0], q1 = S_[1];                                                          \
+    const u32 nAct_ = q0.x & 0xffffu, n_ = nAct_ + (q0.x >> 16);                                 \
+    const u32 first_ = (b_ == b0) ? 0u : nAct_;                                                  \
+    if (first_ == 0 && n_ > 0) VISIT(q0.z, q0.w)                                                 \
+    if (first_ <= 1 && n_ > 1) VISIT(q1.x, q1.y)                                                 \
+    if (first_ <= 2 && n_ > 2) VISIT(q1.z, q1.w)                                                 \
+    if (n_ > 3) {                                                                                \
+      const uint4 q2 = S_[2], q3 = S_[3];                                                        \
+      if (first_ <= 3) VISIT(q2.x, q2.y)                                                         \
+      if (first_ <= 4 && n_ > 4) VISIT(q2.z, q2.w)                                               \
+      if (first_ <= 5 && n_ > 5) VISIT(q3.x, q3.y)                                               \
+      if (first_ <= 6 && n_ > 6) VISIT(q3.z, q3.w)                                               \
+      if (n_ > 7) {                                                                              \
+        const uint4 q4 = S_[4], q5 = S_[5], q6 = S_[6], q7 = S_[7];                              \
+        if (first_ <= 7) VISIT(q4.x, q4.y)                                                       \
+        if (first_ <= 8 && n_ > 8) VISIT(q4.z, q4.w)                                             \
+        if (first_ <= 9 && n_ > 9) VISIT(q5.x, q5.y)                                             \
+        if (first_ <= 10 && n_ > 10) VISIT(q5.z, q5.w)                                           \
+        if (first_ <= 11 && n_ > 11) VISIT(q6.x, q6.y)                                           \
+        if (first_ <= 12 && n_ > 12) VISIT(q6.z, q6.w)                                           \
+        if (first_ <= 13 && n_ > 13) VISIT(q7.x, q7.y)                                           \
+        if (first_ <= 14 && n_ > 14) VISIT(q7.z, q7.w)                                           \
+        for (u32 k_ = max(15u, first_); k_ < n_; k_ += 4) { /* rare long lists: four loads in flight */ \
+          const uint2 *F_ = P.flat + q0.y;                                                       \
+          const uint2 r0 = F_[k_], r1 = F_[min(k_ + 1, n_ - 1)], r2 = F_[min(k_ + 2, n_ - 1)], r3 = F_[min(k_ + 3, n_ - 1)]; \
+          VISIT(r0.x, r0.y)                                                                      \
+          if (k_ + 1 < n_) VISIT(r1.x, r1.y)                                                     \
+          if (k_ + 2 < n_) VISIT(r2.x, r2.y)                                                     \
+          if (k_ + 3 < n_) VISIT(r3.x, r3.y)                                                     \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  }
 
 // scan() + getFirst() through the compact index, for a read with e >= s.
-// Pass 1 visits the whole slot of the bin of s, then only the "starts here" part of the following bins up to the bin
-// of e, and collects the set of hit elements.  The slot's first 32 bytes (header + 3 records) are requested first, the
-// rest of its first half and its second half only when the header says they hold records.  The rare pass 2 (several
-// elements of the winning Order line hit) re-walks the full 16-byte structure, which lists the same candidates.
 template <int OVL>
 __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *chrSlot, const u64 *lineMask, int s, int e, u32 tid1, int rstrand,
                                             u32 &walked) {
@@ -334,66 +369,43 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
   const uint2 cs = chrSlot[tid1 - 1];
   const u32 nb = cs.y;
   if (nb == 0) return 0;
+  const u32 b0 = min((u32) s >> P.sshift, nb - 1), b1 = min((u32) e >> P.sshift, nb - 1);
+  // pass 1: which elements have a passing interval
   u64 hit = 0;
-#define MM_VISIT(RX, RY)                                                                   \
+#define MM_VISIT1(RX, RY)                                                                  \
   {                                                                                        \
     u32 o_; int ie_;                                                                       \
     if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) hit |= 1ull << REC_TYPE(RY); \
     ++walked;                                                                              \
   }
-  const u32 b0 = min((u32) s >> P.sshift, nb - 1), b1 = min((u32) e >> P.sshift, nb - 1);
-  for (u32 b = b0; b <= b1; ++b) {
-    const uint4 *S = P.slots + (size_t) (cs.x + b) * 8;
-    const uint4 q0 = S[0], q1 = S[1];
-    const u32 nAct = q0.x & 0xffffu, n = nAct + (q0.x >> 16);
-    const u32 first = (b == b0) ? 0u : nAct;
-    if (first == 0 && n > 0) MM_VISIT(q0.z, q0.w)
-    if (first <= 1 && n > 1) MM_VISIT(q1.x, q1.y)
-    if (first <= 2 && n > 2) MM_VISIT(q1.z, q1.w)
-    if (n > 3) {
-      const uint4 q2 = S[2], q3 = S[3];
-      if (first <= 3) MM_VISIT(q2.x, q2.y)
-      if (first <= 4 && n > 4) MM_VISIT(q2.z, q2.w)
-      if (first <= 5 && n > 5) MM_VISIT(q3.x, q3.y)
-      if (first <= 6 && n > 6) MM_VISIT(q3.z, q3.w)
-      if (n > 7) {
-        const uint4 q4 = S[4], q5 = S[5], q6 = S[6], q7 = S[7];
-        if (first <= 7) MM_VISIT(q4.x, q4.y)
-        if (first <= 8 && n > 8) MM_VISIT(q4.z, q4.w)
-        if (first <= 9 && n > 9) MM_VISIT(q5.x, q5.y)
-        if (first <= 10 && n > 10) MM_VISIT(q5.z, q5.w)
-        if (first <= 11 && n > 11) MM_VISIT(q6.x, q6.y)
-        if (first <= 12 && n > 12) MM_VISIT(q6.z, q6.w)
-        if (first <= 13 && n > 13) MM_VISIT(q7.x, q7.y)
-        if (first <= 14 && n > 14) MM_VISIT(q7.z, q7.w)
-        for (u32 k = max(15u, first); k < n; k += 4) {   // rare long lists: four loads in flight per round trip
-          const uint2 *F = P.flat + q0.y;
-          const uint2 r0 = F[k], r1 = F[min(k + 1, n - 1)], r2 = F[min(k + 2, n - 1)], r3 = F[min(k + 3, n - 1)];
-          MM_VISIT(r0.x, r0.y)
-          if (k + 1 < n) MM_VISIT(r1.x, r1.y)
-          if (k + 2 < n) MM_VISIT(r2.x, r2.y)
-          if (k + 3 < n) MM_VISIT(r3.x, r3.y)
-        }
-      }
-    }
-  }
-#undef MM_VISIT
+  MM_SLOT_WALK(MM_VISIT1)
+#undef MM_VISIT1
   if (!hit) return 0;
+  // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
   const int low = __ffsll((long long) hit) - 1;
   const u64 cand = hit & lineMask[low];
   if ((cand & (cand - 1)) == 0) return cand;
-  Cand c;
-  if (!locate(P, tid1, s, c)) return 0;
+  // pass 2 (several elements of the winning line were hit): each element's last writer (overlap, distance), then max
+  // overlap, then min distance, ties kept (mmannot.cpp:1023-1028, 1049-1075); the slot lines are in L1 by now
   u64 sel = 0;
   u32 maxO = 0, minD = 0;
   for (u64 cm = cand; cm; cm &= cm - 1) {
     const u32 t = (u32) (__ffsll((long long) cm) - 1);
-    u32 o = 0, d = 0;
-    last_of_type<OVL>(P, c, s, e, rstrand, t, o, d);
-    if (o > maxO) { maxO = o; minD = d; sel = 1ull << t; }
-    else if (o == maxO) {
-      if (d < minD) { minD = d; sel = 1ull << t; }
-      else if (d == minD) sel |= 1ull << t;
+    const bool up = (P.elemUp >> t) & 1, down = (P.elemDown >> t) & 1;
+    u32 o_last = 0, d_last = 0;
+#define MM_VISIT2(RX, RY)                                                                                   \
+  if (REC_TYPE(RY) == t) {                                                                                  \
+    u32 o_; int ie_;                                                                                        \
+    if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) {                                             \
+      o_last = o_; d_last = up ? rd_distance(s, e, ie_) : (down ? rd_distance(s, e, (int) (RX)) : 0u);      \
+    }                                                                                                       \
+  }
+    MM_SLOT_WALK(MM_VISIT2)
+#undef MM_VISIT2
+    if (o_last > maxO) { maxO = o_last; minD = d_last; sel = 1ull << t; }
+    else if (o_last == maxO) {
+      if (d_last < minD) { minD = d_last; sel = 1ull << t; }
+      else if (d_last == minD) sel |= 1ull << t;
     }
   }
   return sel;
