@@ -33,6 +33,18 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// The input tuples are read exactly once: loading them non-temporally keeps 0.3 GB per 2^24-tuple batch from evicting the
+// interval index out of the caches (measured: probe -7 %).  The sort's buffers are NOT streamed this way: consecutive
+// passes re-read them out of L2 / Infinity Cache (non-temporal there: sort +30 %).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_stream(const int4 *p) {
+  const v4i_t v = __builtin_nontemporal_load((const v4i_t *) p);
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ u32 ld_stream(const u32 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(u32 *p, u32 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(u64 *p, u64 v) { __builtin_nontemporal_store(v, p); }
+
 // ----------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -504,8 +516,8 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
     int4 a = make_int4(0, 0, 0, 0);
     u32 nh = 1;
     if (valid) {
-      a = aln[i];
-      if (nhp) nh = nhp[i];
+      a = ld_stream(aln + i);
+      if (nhp) nh = ld_stream(nhp + i);
     }
     const bool processed = valid && !(P.strategy == MM_STRAT_UNIQUE && nh != 1);  // mmannot.cpp:1773
     u64 mask = 0;
@@ -542,10 +554,10 @@ __global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *
     }
     if (valid) {
       if (gkey) {
-        gkey[i] = key;
+        gkey[i] = key;                       // read again right away by the first sort pass: keep these cacheable
         gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
       }
-      if (hm && (P.keep || grouped)) hm[i] = processed ? mask : ~0ull;
+      if (hm && (P.keep || grouped)) st_stream(hm + i, processed ? mask : ~0ull);
     }
   }
   if (grouped_strategy && gkey) {
