@@ -56,10 +56,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
+    # MM_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     # ---------------- annotation (same on every rank) -> device index
@@ -124,12 +132,12 @@ def main():
     masks, sums = ctr.getCounts()
     stats = ctr.stats()
     if strategy != "ratio":
-        masks, sums, stats = merge_counts(masks, sums, stats, device=dev)
+        masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

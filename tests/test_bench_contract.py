@@ -1,0 +1,44 @@
+"""GPU: bench.py keeps its contract — exactly one JSON line on stdout with the agreed keys — for one rank and for two ranks
+(torch.distributed.run, both ranks sharing cuda:0 over gloo: a rehearsal of the multi-GPU path on a one-GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"}
+
+
+def _json_lines(out):
+    return [ln for ln in out.splitlines() if ln.startswith("{")]
+
+
+def test_single_rank_contract(gpu_lib):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch-log2", "20"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = _json_lines(p.stdout.decode())
+    assert len(lines) == 1 and p.stdout.decode().strip() == lines[0]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 0 and d["stats"]["nHits"] == 4 * (1 << 20)
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_share_one_gpu_gloo(gpu_lib):
+    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = _json_lines(p.stdout.decode())
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and "cpu_baseline" not in d
