@@ -50,7 +50,7 @@ def main():
     import torch.distributed as dist
     import mmannot_amd as mm
     from mmannot_amd import _lib, synth
-    from mmannot_amd.dist import merge_counts
+    from mmannot_amd.dist import chain_ratio, merge_counts
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,7 +88,7 @@ def main():
     index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank, bin_shift=args.bin_shift)
     info = index.info()
     stream = torch.cuda.current_stream().cuda_stream
-    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy, stream=stream)
+    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy, stream=stream, defer_ratio=(strategy == "ratio" and world > 1))
 
     # ---------------- inputs: W+K batches per rank, resident in HBM (rank-local stream, rank-local read-name ids)
     B = 1 << args.batch_log2
@@ -129,9 +129,11 @@ def main():
     for s in range(args.warmup, nb):
         run_step(s)
     ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
-    masks, sums = ctr.getCounts()
     stats = ctr.stats()
-    if strategy != "ratio":
+    if strategy == "ratio" and world > 1:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
+        masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev)
+    else:
+        masks, sums = ctr.getCounts()
         masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
     torch.cuda.synchronize()
     if world > 1:

@@ -73,6 +73,7 @@ typedef struct mm_options {
   int32_t strandedness;   /* MM_STRANDED_*                             */
   int32_t strategy;       /* MM_STRAT_* (RANDOM is host-side only: MM_ERR_ARG here) */
   int32_t keep_hit_masks; /* debug/parity: keep the per-hit region sets of the last batch */
+  int32_t defer_ratio;    /* -y ratio only: park each batch's ordered accumulation until mm_ratio_resolve (multi-GPU chaining) */
 } mm_options;
 
 /* One Read as handed to scan() (class Read, mmannot.cpp:846-903), 16 bytes.
@@ -143,6 +144,13 @@ int mm_get_hit_masks(mm_ctx *ctx, uint64_t *out, size_t n);
 int mm_get_hit_intervals(mm_ctx *ctx, uint32_t *counts, uint32_t *idx, size_t cap, size_t *total);
 /* Average number of candidate records visited per alignment in the last batch (profiling aid; requires keep_hit_masks). */
 int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
+
+/* Multi-GPU -y ratio.  regionCounts[set] += 1.0/nHits is a file-order double sum (mmannot.cpp:1730): ranks holding consecutive
+ * blocks of the file chain it.  With mm_options.defer_ratio the batches are probed and sorted as usual but their accumulation is
+ * parked; rank r then calls mm_set_row_sums with the rows of rank r-1 (none for rank 0), mm_ratio_resolve (replays its parked
+ * batches in order), and hands its mm_get_rows on to rank r+1. */
+int mm_set_row_sums(mm_ctx *ctx, const uint64_t *masks, const double *sums, size_t n);
+int mm_ratio_resolve(mm_ctx *ctx);
 
 /* Live timing with HIP events recorded on the context's stream around each phase of
  * mm_annotate_batch / mm_finalize (bench.py's roofline leg).  Off by default. */

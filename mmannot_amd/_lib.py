@@ -36,7 +36,7 @@ class Elements(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("overlap_mode", C.c_int32), ("overlap_value", C.c_float), ("strandedness", C.c_int32),
-                ("strategy", C.c_int32), ("keep_hit_masks", C.c_int32)]
+                ("strategy", C.c_int32), ("keep_hit_masks", C.c_int32), ("defer_ratio", C.c_int32)]
 
 
 class SynthParams(C.Structure):
@@ -65,6 +65,8 @@ SYMBOLS = {
     "mm_get_hit_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mm_get_hit_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_set_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
     "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mm_round_to_uint": (C.c_uint32, [C.c_double]),

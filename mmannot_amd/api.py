@@ -144,11 +144,11 @@ class Counter:
     """Counter (mmannot.cpp:1653-1852) on one GPU."""
 
     def __init__(self, index: IntervalIndex, *, overlap: float = -1.0, strandedness: str = "F", strategy: str = "default",
-                 keep_hit_masks: bool = False, stream: Optional[int] = None):
+                 keep_hit_masks: bool = False, stream: Optional[int] = None, defer_ratio: bool = False):
         self.index = index
         self.strategy = strategy
         opt = Options(overlap_mode_of(overlap), float(np.float32(overlap)), STRANDEDNESS[strandedness], STRATEGY[strategy],
-                      1 if keep_hit_masks else 0)
+                      1 if keep_hit_masks else 0, 1 if defer_ratio else 0)
         h = C.c_void_p()
         check(lib().mm_ctx_create(C.byref(h), index._h, C.byref(opt), C.c_void_p(stream) if stream else None))
         self._h = h
@@ -194,6 +194,15 @@ class Counter:
         sums = np.zeros(max(1, n.value), dtype=np.float64)
         check(lib().mm_get_rows(self._h, masks.ctypes.data, sums.ctypes.data, len(masks), C.byref(n)))
         return masks[:n.value], sums[:n.value]
+
+    def set_row_sums(self, masks: np.ndarray, sums: np.ndarray):
+        """-y ratio chaining: start this counter's rows from the sums of the rank holding the preceding block of the file."""
+        masks = np.ascontiguousarray(masks, dtype=np.uint64); sums = np.ascontiguousarray(sums, dtype=np.float64)
+        check(lib().mm_set_row_sums(self._h, masks.ctypes.data, sums.ctypes.data, len(masks)))
+
+    def resolve_ratio(self):
+        """Replay the batches parked by defer_ratio, in order."""
+        check(lib().mm_ratio_resolve(self._h))
 
     def hit_masks(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint64)

@@ -222,7 +222,7 @@ int main(int argc, char **argv) {
   if (mm_index_from_annotation(&index, an, device, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
   mm_options opt;
   opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
-  opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0;
+  opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0; opt.defer_ratio = 0;
   mm_ctx *ctx = nullptr;
   if (mm_ctx_create(&ctx, index, &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
   const int32_t E = mm_annotation_n_elements(an);

@@ -1295,11 +1295,16 @@ struct mm_ctx {
   u64 qcap = 0;
   u32 *d_grpRem = nullptr;
   u64 *d_grpU = nullptr;
+  // -y ratio with defer_ratio: each batch's slot-sorted (slot, NH) pairs are parked here until mm_ratio_resolve
+  struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr; size_t n = 0; };
+  std::vector<Run> runs;
   // optional live timing (HIP events on the context's stream), see mm_set_profiling
   bool profiling = false;
   struct Span { int phase; hipEvent_t a, b; };
   std::vector<Span> spans;
 };
+
+static void free_runs(mm_ctx *c);
 
 struct PhaseTimer {  // records an event pair around a group of launches when profiling is on
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
@@ -1573,6 +1578,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   if (!c) return;
   (void) hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
+  free_runs(c);
   ctx_free_batch(c);
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
@@ -1595,6 +1601,7 @@ extern "C" int mm_reset(mm_ctx *c) {
   if (c->qcap) {
     HIPCHK(hipMemsetAsync(c->d_grpRem, 0, c->qcap * 4, c->stream)); HIPCHK(hipMemsetAsync(c->d_grpU, 0, c->qcap * 8, c->stream));
   }
+  free_runs(c);
   c->finalized = false;
   c->last_n = 0;
   return MM_OK;
@@ -1687,6 +1694,30 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   return MM_OK;
 }
 
+__global__ __launch_bounds__(256) void k_seed_rows(const u64 *__restrict__ masks, const double *__restrict__ sums, u32 n, GlobalTable G) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || masks[i] == 0) return;
+  const u32 s = gt_find_or_insert(G, masks[i]);
+  if (s != NO_KEY) G.sum[s] = sums[i];
+}
+
+// ordered accumulation of one batch's slot-sorted pairs (see k_ratio_rows)
+static int ratio_accumulate(mm_ctx *c, const u32 *keys, const u32 *vals, const u32 *info, size_t n) {
+  const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
+  HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
+  hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, keys, info, c->d_seg, c->d_seg + GT_CAP);
+  hipLaunchKernelGGL(k_ratio_tiles, dim3((u32) (n / RATIO_CHUNK + 1)), dim3(256), 0, c->stream, keys, vals, info, c->G, c->d_tileTot, c->d_tileK);
+  hipLaunchKernelGGL(k_ratio_rows, dim3(GT_CAP / RATIO_SLOTS_PER_WG), dim3(RATIO_THREADS), 0, c->stream, vals, c->d_seg, c->d_seg + GT_CAP, c->G,
+                     c->d_tileTot, c->d_tileK);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+static void free_runs(mm_ctx *c) {
+  for (auto &r : c->runs) { (void) hipFree(r.k); (void) hipFree(r.v); (void) hipFree(r.info); }
+  c->runs.clear();
+}
+
 extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *nh, size_t n, uint64_t qid_bound, int on_device) {
   if (!c) return fail(MM_ERR_ARG, "mm_annotate_batch: null context");
   if (c->finalized) return fail(MM_ERR_STATE, "mm_annotate_batch: context already finalized (call mm_reset)");
@@ -1751,11 +1782,17 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     if (dflt)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
-    else {  // 16 key bits = two passes: the sorted pairs are back in A
-      HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
-      hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_M, c->d_seg, c->d_seg + GT_CAP);
-      hipLaunchKernelGGL(k_ratio_tiles, dim3((u32) (n / RATIO_CHUNK + 1)), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_M, c->G, c->d_tileTot, c->d_tileK);
-      hipLaunchKernelGGL(k_ratio_rows, dim3(GT_CAP / RATIO_SLOTS_PER_WG), dim3(RATIO_THREADS), 0, c->stream, c->d_vA, c->d_seg, c->d_seg + GT_CAP, c->G, c->d_tileTot, c->d_tileK);
+    else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
+      mm_ctx::Run r;
+      r.n = n;
+      HIPCHK(hipMalloc((void **) &r.k, n * 4)); HIPCHK(hipMalloc((void **) &r.v, n * 4)); HIPCHK(hipMalloc((void **) &r.info, INFO_WORDS * 4));
+      HIPCHK(hipMemcpyAsync(r.k, c->d_kA, n * 4, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(r.v, c->d_vA, n * 4, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(r.info, c->d_M, INFO_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));
+      c->runs.push_back(r);
+    } else {
+      rc = ratio_accumulate(c, c->d_kA, c->d_vA, c->d_M, n);
+      if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
   }
@@ -1787,6 +1824,39 @@ extern "C" int mm_finalize(mm_ctx *c) {
   }
   c->finalized = true;
   return mm_sync(c);
+}
+
+// Multi-GPU -y ratio: the double sums are order dependent (mmannot.cpp:1730), so ranks that each hold a contiguous block of the
+// file chain them: rank r seeds its rows with rank r-1's sums (mm_set_row_sums), replays its parked batches in order
+// (mm_ratio_resolve) and passes its rows on.
+extern "C" int mm_set_row_sums(mm_ctx *c, const uint64_t *masks, const double *sums, size_t n) {
+  if (!c || (n && (!masks || !sums))) return fail(MM_ERR_ARG, "mm_set_row_sums: null argument");
+  if (c->opt.strategy != MM_STRAT_RATIO) return fail(MM_ERR_STATE, "mm_set_row_sums: only meaningful under -y ratio");
+  if (n == 0) return MM_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  u64 *dm = nullptr; double *ds = nullptr;
+  HIPCHK(hipMalloc((void **) &dm, n * 8)); HIPCHK(hipMalloc((void **) &ds, n * 8));
+  HIPCHK(hipMemcpyAsync(dm, masks, n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(ds, sums, n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_seed_rows, dim3((u32) ((n + 255) / 256)), dim3(256), 0, c->stream, dm, ds, (u32) n, c->G);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void) hipFree(dm); (void) hipFree(ds);
+  if (e != hipSuccess) return fail(MM_ERR_HIP, std::string("mm_set_row_sums: ") + hipGetErrorString(e));
+  return check_table(c);
+}
+
+extern "C" int mm_ratio_resolve(mm_ctx *c) {
+  if (!c) return fail(MM_ERR_ARG, "mm_ratio_resolve: null context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  for (auto &r : c->runs) {
+    PhaseTimer t(c, MM_PHASE_MERGE);
+    int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  free_runs(c);
+  return check_table(c);
 }
 
 extern "C" int mm_set_profiling(mm_ctx *c, int on) {

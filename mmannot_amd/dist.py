@@ -46,3 +46,53 @@ def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], dev
     out = dense.cpu().numpy()
     mk = dictionary.cpu().numpy().view(np.uint64)
     return mk, out[:len(mk)].astype(np.float64), {k: int(v) for k, v in zip(names, out[len(mk):])}
+
+
+def chain_ratio(counter, stats: Dict[str, int], device=None, group=None):
+    """-y ratio across ranks that hold consecutive blocks of the file (rank order = file order).  Every rank has already probed
+    and sorted its batches with defer_ratio; the ordered double accumulation (mmannot.cpp:1730) is then chained: receive the
+    rows of rank-1, seed, replay the parked batches, send the rows to rank+1; the last rank broadcasts the final table.
+    Returns (masks, sums, stats) identical on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        counter.resolve_ratio()
+        m, s = counter.getCounts()
+        return m, s, stats
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+
+    def send_rows(m, s, dst):
+        dist.send(torch.tensor([len(m)], dtype=torch.int64, device=dev), dst=dst, group=group)
+        if len(m):
+            dist.send(torch.from_numpy(m.view(np.int64).copy()).to(dev), dst=dst, group=group)
+            dist.send(torch.from_numpy(s.view(np.int64).copy()).to(dev), dst=dst, group=group)   # the bit patterns travel, not rounded values
+
+    def recv_rows(src):
+        n = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.recv(n, src=src, group=group)
+        k = int(n.item())
+        if k == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.float64)
+        m = torch.zeros(k, dtype=torch.int64, device=dev); s = torch.zeros(k, dtype=torch.int64, device=dev)
+        dist.recv(m, src=src, group=group); dist.recv(s, src=src, group=group)
+        return m.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.float64)
+
+    if rank > 0:
+        m, s = recv_rows(rank - 1)
+        counter.set_row_sums(m, s)
+    counter.resolve_ratio()
+    masks, sums = counter.getCounts()
+    if rank < ws - 1:
+        send_rows(masks, sums, rank + 1)
+    # final table from the last rank to everybody
+    n = torch.tensor([len(masks)], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=ws - 1, group=group)
+    k = int(n.item())
+    m = torch.zeros(k, dtype=torch.int64, device=dev); s = torch.zeros(k, dtype=torch.int64, device=dev)
+    if rank == ws - 1 and k:
+        m.copy_(torch.from_numpy(masks.view(np.int64).copy())); s.copy_(torch.from_numpy(sums.view(np.int64).copy()))
+    if k:
+        dist.broadcast(m, src=ws - 1, group=group); dist.broadcast(s, src=ws - 1, group=group)
+    names = list(stats.keys())
+    st = torch.tensor([stats[x] for x in names], dtype=torch.int64, device=dev)
+    dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
+    return m.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.float64), {x: int(v) for x, v in zip(names, st.cpu().tolist())}

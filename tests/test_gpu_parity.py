@@ -187,3 +187,42 @@ def test_qid_bound_too_small_is_an_error_not_a_fault(gpu_lib):
     with pytest.raises(mm.MMError):
         ctr.sync()
     ctr.close(); index.close()
+
+
+def test_ratio_chain_across_contexts(gpu_lib, oracle):
+    """Multi-GPU -y ratio in miniature: two contexts hold consecutive blocks of one stream, park their accumulation
+    (defer_ratio) and chain the per-row sums; the result must be bit-identical to one context over the whole stream and to
+    the CPU oracle."""
+    from mmannot_amd import synth
+    mm = gpu_lib
+    an = synth.synth_annotation("hs38", seed=9, scale=0.05)
+    n = 2_400_000
+    rng = np.random.default_rng(6)
+    pick = rng.integers(0, len(an.start), n)
+    st = np.maximum(1, an.start[pick] + rng.integers(-60, 80, n))
+    t = dict(tid=an.chr[pick].astype(np.int32), start=st.astype(np.int64), end=(st + 99).astype(np.int64),
+             strand=rng.integers(0, 2, n).astype(np.uint8), nh=rng.integers(1, 40, n).astype(np.uint32), qid=np.arange(n, dtype=np.int64))
+    desc = oracle.ConfigDesc.from_json(an.config)
+    ref = oracle.run(desc, an.as_index_dict(), t, overlap=-1.0, strandedness="F", strategy="ratio")
+    cfg = mm.Config.from_json(an.config)
+    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes)
+    aln = mm.pack_alignments(t["tid"], t["start"], t["end"], t["strand"], t["qid"])
+    cut = 1_000_001
+    a = mm.Counter(index, strategy="ratio", defer_ratio=True)
+    b = mm.Counter(index, strategy="ratio", defer_ratio=True)
+    for lo, hi in ((0, 400_000), (400_000, cut)):
+        a.add_batch(aln[lo:hi], t["nh"][lo:hi], n); a.sync()
+    for lo, hi in ((cut, 1_700_000), (1_700_000, n)):
+        b.add_batch(aln[lo:hi], t["nh"][lo:hi], n); b.sync()
+    a.flush(); b.flush()
+    a.resolve_ratio()
+    ma, sa = a.getCounts()
+    b.set_row_sums(ma, sa)
+    b.resolve_ratio()
+    mb, sb = b.getCounts()
+    sta, stb = a.stats(), b.stats()
+    assert {k: sta[k] + stb[k] for k in sta} == ref.stats
+    got = dict(zip(mb.tolist(), sb.view(np.uint64).tolist()))
+    want = dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
+    assert got == want
+    a.close(); b.close(); index.close()
