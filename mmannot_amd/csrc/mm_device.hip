@@ -8,15 +8,18 @@
 //   Counter::read flush           :1783-1792   -> k_flush_pending
 //   Counter::getCounts / dump     :1803-1818   -> mm_get_rows / mm_get_stats
 //
-// This is not a translation of the reference's walk.  The reference sorts intervals by start,
-// jumps through a 16 kb bin table keyed on interval *ends* and walks forward; long intervals
-// make that walk long and lane-divergent.  Here the index is a "checkpointed sweep":
-//   bins[b]   = { first interval whose start >= b*W ,  offset of bin b's active list }
-//   act[...]  = copies of the interval records that are open at b*W (start < b*W <= end+1),
-//               in index order
-// so the candidates of a read starting in bin b are exactly  act(b) ++ iv[first(b) .. start<=read.end],
-// visited in the reference's index order (which matters: EvaluationStructure::set is last-writer-wins).
-// See DESIGN.md for the equivalence argument, including the "leading isBefore run" quirk.
+// This is not a translation of the reference's walk.  The reference sorts intervals by start, jumps through a 16 kb
+// bin table keyed on interval *ends* and walks forward; long intervals make that walk long and lane-divergent.  Here the
+// index is a "checkpointed sweep": the candidates of a read starting in bin b (width W) are
+//   act(b)  = the intervals open at the bin's left edge (start < b*W <= end+1), in index order, followed by
+//   iv(b..) = the intervals starting at or after b*W, in index order, while start <= read.end,
+// visited in the reference's index order (which matters: EvaluationStructure::set is last-writer-wins).  Two encodings:
+//   * compact slots (probe_slots): one 128-B line per bin with up to 15 packed 8-B records - every read with end >= start;
+//   * full 16-B records + bins + active lists (probe_one): reads without CIGAR operations (they need the "leading
+//     isBefore run" rule, which uses each record's prefix-max of ends) and the -M interval listing.
+// Downstream of the probe: multi-hit records are stably radix-sorted by read-name id and reduced per name (k_rs_*,
+// k_chunk_default); -y ratio sorts by element set and accumulates each row's doubles in file order, exactly but in
+// parallel (k_ratio_tiles, k_ratio_rows).  See DESIGN.md.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
