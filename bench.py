@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — annotated alignments / second of the overlap-and-count hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2] [--batch-log2 B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--batch-log2 B]
 
 One process per GPU (the driver launches N>1 through torch.distributed.run; backend "nccl" = RCCL).
 A step = one batch of 2^B synthetic alignment tuples, generated on the device beforehand (inputs are
@@ -14,6 +14,10 @@ Workloads (BASELINE.json configs):
       windows of 2^16 tuples), HS38-scale synthetic annotation (~1.27 M intervals, 22 Order elements),
       -y default -s F -l -1.  This is the configuration the north-star target is quoted on.
   c2: 50 bp reads, NH = 1, TAIR10-scale annotation (~0.55 M intervals, 14 elements).
+  c4: 100 bp read pairs (mates share a name, opposite strands), Flybase6-shaped annotation with introns and
+      vicinity (-d/-D 1000), -l 50, under -s U: the reference's parser rejects -s FR, so -s U is
+      the only setting of this configuration that has an oracle.
+  c5: NH = 1..100 groups, -y ratio, HS38-scale annotation.
 """
 from __future__ import annotations
 
@@ -31,16 +35,30 @@ sys.path.insert(0, ROOT)
 
 B_ALG_PROBE = 32.0  # algorithmic bytes / alignment of the probe kernel: 16 B tuple + 16 B index
 
+# BASELINE.json configs -> (annotation shape, scale, read length, NH max, scatter window log2, mate distance, strategy, -l, -s)
+WORKLOADS = {
+    "c2": dict(shape="tair10", scale=1.0, read_len=50, nh_max=1, scatter=0, pair=0, strategy="default", overlap=-1.0, strand="F",
+               name="c2: synthetic 50bp SE reads, NH=1, TAIR10-scale annotation, -y default -s F -l -1"),
+    "c3": dict(shape="hs38", scale=1.5, read_len=100, nh_max=20, scatter=16, pair=0, strategy="default", overlap=-1.0, strand="F",
+               name="c3: synthetic 100bp SE reads, NH=1..20 groups, HS38-scale annotation, -y default -s F -l -1"),
+    "c4": dict(shape="flybase6", scale=1.0, read_len=100, nh_max=1, scatter=0, pair=250, strategy="default", overlap=50.0, strand="U",
+               name="c4: synthetic 2x100bp read pairs, Flybase6-shaped annotation with introns + vicinity 1000, -y default -s U -l 50"),
+    "c5": dict(shape="hs38", scale=1.5, read_len=100, nh_max=100, scatter=16, pair=0, strategy="ratio", overlap=-1.0, strand="F",
+               name="c5: synthetic 100bp SE reads, NH=1..100 groups, HS38-scale annotation, -y ratio -s F -l -1"),
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-log2", type=int, default=24)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--bin-shift", type=int, default=0, help="log2 of the index bin width (0 = the library's choice)")
+    ap.add_argument("--scatter-log2", type=int, default=-1, help="informational: window over which a read's hits are spread (0 = hits adjacent, "
+                    "an aligner's own output order; default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--from-host", action="store_true", help="informational: tuples start in pinned host memory (PCIe-inclusive rate, never `value` of record)")
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
@@ -71,24 +89,18 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     # ---------------- annotation (same on every rank) -> device index
-    if args.workload == "c3":
-        an = synth.synth_annotation("hs38", seed=args.seed, scale=1.5, keep_genes=(rank == 0 and world == 1))
-        read_len, nh_max, scatter = 100, 20, 16
-        wname = "c3: synthetic 100bp SE reads, NH=1..20 groups, HS38-scale annotation, -y default -s F -l -1"
-    elif args.workload == "c5":
-        an = synth.synth_annotation("hs38", seed=args.seed, scale=1.5, keep_genes=False)
-        read_len, nh_max, scatter = 100, 100, 16
-        wname = "c5: synthetic 100bp SE reads, NH=1..100 groups, HS38-scale annotation, -y ratio -s F -l -1"
-    else:
-        an = synth.synth_annotation("tair10", seed=args.seed, scale=1.0, keep_genes=(rank == 0 and world == 1))
-        read_len, nh_max, scatter = 50, 1, 0
-        wname = "c2: synthetic 50bp SE reads, NH=1, TAIR10-scale annotation, -y default -s F -l -1"
-    strategy = "ratio" if args.workload == "c5" else "default"
+    wl = dict(WORKLOADS[args.workload])
+    if args.scatter_log2 >= 0:
+        wl["scatter"] = args.scatter_log2
+        wl["name"] += f" [hits of a read spread over 2^{args.scatter_log2} tuples]"
+    an = synth.synth_annotation(wl["shape"], seed=args.seed, scale=wl["scale"], keep_genes=(rank == 0 and world == 1 and wl["strategy"] == "default"))
+    read_len, nh_max, scatter, pair, strategy, wname = wl["read_len"], wl["nh_max"], wl["scatter"], wl["pair"], wl["strategy"], wl["name"]
     cfg = mm.Config.from_json(an.config)
     index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank, bin_shift=args.bin_shift)
     info = index.info()
     stream = torch.cuda.current_stream().cuda_stream
-    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy, stream=stream, defer_ratio=(strategy == "ratio" and world > 1))
+    ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy, stream=stream,
+                     defer_ratio=(strategy == "ratio" and world > 1))
 
     # ---------------- inputs: W+K batches per rank, resident in HBM (rank-local stream, rank-local read-name ids)
     B = 1 << args.batch_log2
@@ -98,7 +110,7 @@ def main():
     for s in range(nb):
         a = torch.empty((B, 4), dtype=torch.int32, device=dev)
         h = torch.empty(B, dtype=torch.int32, device=dev) if nh_max > 1 else None
-        p = _lib.SynthParams(args.seed * 1000003 + rank, s * B, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter)
+        p = _lib.SynthParams(args.seed * 1000003 + rank, s * B, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
         _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), h.data_ptr() if h is not None else None, B, C.byref(p), stream))
         alns.append(a); nhs.append(h)
     torch.cuda.synchronize()
@@ -178,8 +190,8 @@ def main():
         if args.from_host:
             out["metric"] = "annotated alignments/sec INCLUDING the PCIe copy of pinned host tuples (informational)"
         if not args.no_cpu_baseline and world == 1 and strategy == "default":
-            port = cpu_baseline(args, an, read_len, nh_max, scatter, chr_len)
-            ref = cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, cfg)
+            port = cpu_baseline(args, an, wl, chr_len)
+            ref = cpu_baseline_reference(args, an, wl, chr_len, index, cfg)
             if ref is not None:
                 ref["port_single_thread"] = {k: port[k] for k in ("value", "sample")}
                 out["cpu_baseline"] = ref
@@ -191,23 +203,23 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, an, read_len, nh_max, scatter, chr_len):
+def cpu_baseline(args, an, wl, chr_len):
     """The CPU restatement of the path (oracle/mm_oracle.c, kind "port", one thread) on a prefix of rank 0's stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth_ref as sr
     from oracle import mm_oracle as mo
     n = 1 << args.cpu_sample_log2
-    t = sr.synth_tuples(args.seed * 1000003, 0, n, read_len, nh_max, chr_len, scatter)
+    t = sr.synth_tuples(args.seed * 1000003, 0, n, wl["read_len"], wl["nh_max"], chr_len, wl["scatter"], wl["pair"])
     desc = mo.ConfigDesc.from_json(an.config)
     t0 = time.perf_counter()
-    r = mo.run(desc, an.as_index_dict(), t, overlap=-1.0, strandedness="F", strategy="default")
+    r = mo.run(desc, an.as_index_dict(), t, overlap=wl["overlap"], strandedness=wl["strand"], strategy="default")
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
             "sample": f"first 2^{args.cpu_sample_log2} alignments of rank 0's stream, oracle/mm_oracle.c single thread, {dt:.1f} s",
             "stats": r.stats}
 
 
-def cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, cfg):
+def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     """The reference itself (oracle/_ref/mmannot_patched = v1.1 + the one-line strand fix that makes -s F deterministic,
     SURVEY.md F1), compiled in the build container, on a bounded sample of the same workload: the synthetic GTF and
     configuration as files, S BAM shards of 2^21 alignments of rank 0's stream, `-t S` (the reference parallelises over
@@ -223,6 +235,8 @@ def cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, 
     import mmannot_amd as mm
     from mmannot_amd import synth
     from oracle import mm_oracle as mo
+    read_len, nh_max, scatter = wl["read_len"], wl["nh_max"], wl["scatter"]
+    flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else [])
     S = max(1, min(16, os.cpu_count() or 1))
     n = 1 << 21
     d = tempfile.mkdtemp(prefix="mmbench")
@@ -231,7 +245,7 @@ def cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, 
     chroms = [(c, int(l)) for c, l in zip(an.chr_names, an.chr_len)]
     shards, first_tuples = [], None
     for i in range(S):
-        t = sr.synth_tuples(args.seed * 1000003, i * n, n, read_len, nh_max, chr_len, scatter)
+        t = sr.synth_tuples(args.seed * 1000003, i * n, n, read_len, nh_max, chr_len, scatter, wl["pair"])
         if i == 0:
             first_tuples = t
         body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"],
@@ -242,14 +256,14 @@ def cpu_baseline_reference(args, an, read_len, nh_max, scatter, chr_len, index, 
 
     def run(files, threads, out):
         t0 = time.perf_counter()
-        p = subprocess.run([ref, "-a", gtf, "-c", cfgp, "-s", "F", "-t", str(threads), "-o", out, "-r"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        p = subprocess.run([ref, "-a", gtf, "-c", cfgp] + flags + ["-t", str(threads), "-o", out, "-r"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()[-500:]
         return time.perf_counter() - t0
     t_fixed = run([one], 1, os.path.join(d, "t0.tsv"))
     t_one = run([shards[0]], 1, os.path.join(d, "t1.tsv"))
     t_full = run(shards, S, os.path.join(d, "tS.tsv"))
     # bench-time parity: GPU path on shard 0's tuples == the reference's table for shard 0
-    ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy="default")
+    ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy="default")
     t = first_tuples
     # the reference resolves chromosomes by name: reads on a chromosome without intervals are 'unknown' to it
     has_iv = np.zeros(an.n_chromosomes + 1, dtype=bool); has_iv[np.unique(an.chr)] = True

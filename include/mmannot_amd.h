@@ -142,7 +142,9 @@ int mm_get_hit_masks(mm_ctx *ctx, uint64_t *out, size_t n);
  * counts[n] always; idx (capacity cap) may be NULL to learn *total first.  Requires keep_hit_masks; the batch's tuples must
  * still be valid (device batches: not yet overwritten by the caller). */
 int mm_get_hit_intervals(mm_ctx *ctx, uint32_t *counts, uint32_t *idx, size_t cap, size_t *total);
-/* Average number of candidate records visited per alignment in the last batch (profiling aid; requires keep_hit_masks). */
+/* Profiling aids since the last mm_reset.  out[0]: candidate records visited by the probe (requires keep_hit_masks);
+ * out[1]: batches whose multi-hit records arrived already grouped by read name (non-decreasing qids, as in an aligner's
+ * unsorted output) and therefore skipped the name sort. */
 int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
 
 /* Multi-GPU -y ratio.  regionCounts[set] += 1.0/nHits is a file-order double sum (mmannot.cpp:1730): ranks holding consecutive
@@ -214,6 +216,8 @@ typedef struct mm_synth_params {
   int32_t n_chromosomes;
   const int64_t *chr_len;  /* host array [n_chromosomes]                                       */
   uint32_t scatter_log2;   /* hits of one read are spread over windows of 2^scatter_log2 tuples */
+  uint32_t pair_insert;    /* > 0 (needs nh_max 1): tuples 2p, 2p+1 are mates - one name, opposite strands,
+                            * starts pair_insert + 0..63 apart (BASELINE.json configs[3])          */
 } mm_synth_params;
 int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_params *p, void *stream);
 

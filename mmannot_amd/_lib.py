@@ -41,7 +41,7 @@ class Options(C.Structure):
 
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first", C.c_uint64), ("read_len", C.c_int32), ("nh_max", C.c_int32),
-                ("n_chromosomes", C.c_int32), ("chr_len", C.c_void_p), ("scatter_log2", C.c_uint32)]
+                ("n_chromosomes", C.c_int32), ("chr_len", C.c_void_p), ("scatter_log2", C.c_uint32), ("pair_insert", C.c_uint32)]
 
 
 _lib = None

@@ -214,6 +214,12 @@ class Counter:
         check(lib().mm_get_walk_stats(self._h, a))
         return int(a[0])
 
+    def grouped_batches(self) -> int:
+        """Batches whose multi-hit records were already grouped by read name (no name sort needed)."""
+        a = (C.c_uint64 * 2)()
+        check(lib().mm_get_walk_stats(self._h, a))
+        return int(a[1])
+
     PHASES = ("h2d", "probe", "compact", "sort", "merge", "flush")
 
     def set_profiling(self, on: bool):

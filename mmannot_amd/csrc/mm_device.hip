@@ -73,7 +73,8 @@ enum { INFO_M = 0,      // number of records in the grouping pipeline
        INFO_QINV = 1,   // max over ~qid of the multi-hit records = ~(smallest qid)
        INFO_QMAX = 2,   // largest qid of the multi-hit records
        INFO_BIGNH = 3,  // some multi-hit record has NH >= 65535: payloads carry the record index instead of (slot, NH)
-       INFO_WORDS = 4 };
+       INFO_UNSORTED = 4,  // the multi-hit records' qids are not already non-decreasing in file order (name-grouped input is)
+       INFO_WORDS = 5 };
 
 __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits needed for keys in [0, span]
   int b = 1;
@@ -83,6 +84,7 @@ __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits need
 // sort-key width of this batch: multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys)
 __device__ __forceinline__ int batch_key_bits(const unsigned int *info, int fixed_bits) {
   if (fixed_bits) return fixed_bits;
+  if (!info[INFO_UNSORTED]) return 1;   // already grouped by name: the compacting first pass is all that is needed
   const unsigned int qmin = ~info[INFO_QINV], qmax = info[INFO_QMAX];
   return qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
 }
@@ -614,21 +616,66 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
   return true;
 }
 
+// Rows of `hist` (nblk entries each): 0..255 the digit counts per tile; for the first pass of the name sort also
+//   256 the tile's number of pairs, 257 / 258 its first / last key (NO_KEY: none) - see the order check below.
+#define RS_ROW_COUNT 256
+#define RS_ROW_FIRST 257
+#define RS_ROW_LAST 258
+#define RS_ROWS 259
+
+// Order check (first pass of the name sort only): an aligner writes the hits of one read one after the other, and read-name
+// ids are handed out in order of first appearance, so the qids of such a file are already non-decreasing and the "sort"
+// only has to compact.  Every record is compared with the nearest earlier record of the pipeline: inside a wave by ballot,
+// between the 64 wave-segments of a tile through LDS, between tiles by k_rs_scan_tot.  Any inversion sets INFO_UNSORTED
+// and the batch takes the general path.
 template <bool FIRST>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ info,
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ info,
                                                         size_t n, int rebase, int shift, int fixed_bits, u32 *__restrict__ hist, u32 nblk) {
   __shared__ u32 h[256];
+  __shared__ u32 segF[RS_ROUNDS * 4], segL[RS_ROUNDS * 4];
+  __shared__ u32 tileCnt, tileBad;
   if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
+  const bool order = FIRST && rebase;
+  const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   h[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { tileCnt = 0; tileBad = 0; }
   __syncthreads();
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
+  u32 bad = 0, wcnt = 0;
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
-    u32 k, v;
-    if (rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    u32 k = 0, v;
+    const bool ok = rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v);
+    if (ok) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    if (order) {
+      const u64 vm = __ballot(ok);
+      const u64 below = vm & ((1ull << lane) - 1ull);
+      const u32 pk = __shfl(k, below ? 63 - __clzll((long long) below) : 0);
+      if (ok && below && pk > k) bad = 1;
+      const u32 kf = __shfl(k, vm ? __ffsll((long long) vm) - 1 : 0), kl = __shfl(k, vm ? 63 - __clzll((long long) vm) : 0);
+      if (lane == 0) { segF[r * 4 + w] = vm ? kf : NO_KEY; segL[r * 4 + w] = vm ? kl : NO_KEY; wcnt += (u32) __popcll(vm); }
+    }
   }
+  if (order && lane == 0) atomicAdd(&tileCnt, wcnt);
+  if (order && __ballot(bad) && lane == 0) tileBad = 1;
   __syncthreads();
   hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  if (order && w == 0) {   // the tile's 64 segments in file order (segment = round * 4 + wave), one per lane
+    const u32 F = segF[lane], L = segL[lane];
+    const bool has = F != NO_KEY;
+    const u64 vm = __ballot(has);
+    const u64 below = vm & ((1ull << lane) - 1ull);
+    const u32 pl = __shfl(L, below ? 63 - __clzll((long long) below) : 0);
+    if (__ballot(has && below && pl > F)) bad = 1;   // wave-wide, so that thread 0 knows
+    const u32 tf = __shfl(F, vm ? __ffsll((long long) vm) - 1 : 0), tl = __shfl(L, vm ? 63 - __clzll((long long) vm) : 0);
+    if (lane == 0) {
+      hist[(size_t) RS_ROW_COUNT * nblk + blockIdx.x] = tileCnt;
+      hist[(size_t) RS_ROW_FIRST * nblk + blockIdx.x] = vm ? tf : NO_KEY;
+      hist[(size_t) RS_ROW_LAST * nblk + blockIdx.x] = vm ? tl : NO_KEY;
+    }
+  }
+  // one flag for the whole batch: on unsorted input nearly every tile finds an inversion, so look before the atomic
+  if (order && threadIdx.x == 0 && (tileBad || bad) && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
 }
 
 // one workgroup per digit: exclusive scan of its row of per-tile counts
@@ -662,15 +709,43 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u3
   if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, u32 *__restrict__ info, int shift, int fixed_bits) {
+__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, u32 *__restrict__ info, int shift, int fixed_bits,
+                                                     const u32 *__restrict__ hist, u32 nblk, int order, u64 *__restrict__ walkstat) {
   __shared__ u32 s[256];
+  __shared__ u32 wmax[4];
   if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
+  if (order) {   // between tiles: a tile's first key may not be below the largest last key of the tiles before it
+    const u32 *first = hist + (size_t) RS_ROW_FIRST * nblk, *last = hist + (size_t) RS_ROW_LAST * nblk;
+    const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 carry = 0, bad = 0;
+    for (u32 base = 0; base < nblk; base += 256) {
+      const u32 i = base + threadIdx.x;
+      const u32 F = i < nblk ? first[i] : NO_KEY;
+      const u32 v = F != NO_KEY ? last[i] : 0u;
+      u32 x = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off);
+        if ((int) lane >= off) x = max(x, y);
+      }
+      if (lane == 63) wmax[w] = x;
+      __syncthreads();
+      u32 before = carry, all = carry;
+      for (u32 q = 0; q < 4; ++q) { if (q < w) before = max(before, wmax[q]); all = max(all, wmax[q]); }
+      const u32 prev = __shfl_up(x, 1);
+      if (lane > 0) before = max(before, prev);
+      if (F != NO_KEY && F < before) bad = 1;
+      carry = all;
+      __syncthreads();
+    }
+    if (bad) atomicOr(&info[INFO_UNSORTED], 1u);
+  }
   s[threadIdx.x] = rowTotal[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 acc = 0;
     for (int d = 0; d < 256; ++d) { const u32 v = s[d]; s[d] = acc; acc += v; }
     if (shift == 0) info[INFO_M] = acc;   // the first pass compacts: this is the number of pairs in the pipeline
+    if (order && acc && !info[INFO_UNSORTED]) atomicAdd(&walkstat[1], 1ull);   // (reported by mm_get_walk_stats)
   }
   __syncthreads();
   rowTotal[threadIdx.x] = s[threadIdx.x];
@@ -699,6 +774,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const size_t lim = FIRST ? n : (size_t) info[INFO_M];
   if (lo >= lim) return;
+  // name-grouped input (see k_rs_hist): one "digit" for everything, i.e. a stable compaction in file order
+  const bool presorted = FIRST && rebase && !info[INFO_UNSORTED];
+  const u32 dmask = presorted ? 0u : 255u;
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   cntw[0][t] = 0; cntw[1][t] = 0; cntw[2][t] = 0; cntw[3][t] = 0;
   __syncthreads();
@@ -709,10 +787,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const u32 li = wbase + (u32) r * 64u + lane;
     kreg[r] = 0; vreg[r] = 0;
-    if (rs_load<FIRST>(kin, vin, info, lo + li, n, rebase, kreg[r], vreg[r])) {
-      vmask |= 1u << r;
-      atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
-    }
+    const bool ok = rs_load<FIRST>(kin, vin, info, lo + li, n, rebase, kreg[r], vreg[r]);
+    if (ok) vmask |= 1u << r;
+    if (presorted) {   // (wave-uniform) all pairs count for digit 0: one add per wave instead of 64 colliding atomics
+      const u32 c = (u32) __popcll(__ballot(ok));
+      if (lane == 0) cntw[w][0] += c;
+    } else if (ok) atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
   }
   __syncthreads();
   {  // B: thread t owns digit t
@@ -728,14 +808,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     u32 loff = x - tot;
     for (u32 q = 0; q < w; ++q) loff += wsum[q];
     if (t == 255) tcountS = loff + tot;                  // number of pairs this tile holds
-    goff[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x] - loff;
+    goff[t] = presorted ? hist[(size_t) RS_ROW_COUNT * nblk + blockIdx.x] : base[t] + hist[(size_t) t * nblk + blockIdx.x] - loff;
     cntw[0][t] = loff; cntw[1][t] = loff + c0; cntw[2][t] = loff + c0 + c1; cntw[3][t] = loff + c0 + c1 + c2;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {  // C: wave-private, LDS operations of one wave execute in program order
     const bool valid = (vmask >> r) & 1u;
-    const u32 d = (kreg[r] >> shift) & 255u;
+    const u32 d = (kreg[r] >> shift) & dmask;
     u64 peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -752,7 +832,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   const u32 tcount = tcountS;
   for (u32 i = t; i < tcount; i += RS_THREADS) {  // D
     const u32 k = lkey[i];
-    const u32 g = goff[(k >> shift) & 255u] + i;
+    const u32 g = goff[(k >> shift) & dmask] + i;
     kout[g] = k; vout[g] = lval[i];
   }
 }
@@ -1197,6 +1277,7 @@ struct SynthDev {
   u64 seed, first;
   int read_len, nh_max, nchr;
   u32 scatter_log2;
+  u32 pair_insert;   // > 0: tuples 2p, 2p+1 are the mates of pair p (same name, opposite strands, starts this far apart + 0..63)
   u64 cum[65];   // cumulative chromosome lengths
 };
 
@@ -1229,18 +1310,20 @@ __global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restric
       nh = (u32) k + 1;
       qid = blk * K + k;
     }
+    u64 mate = 0, foot = (u64) S.read_len;   // foot: what has to fit on the chromosome
+    if (S.pair_insert) { mate = L & 1ull; L >>= 1; qid = L; foot += (u64) S.pair_insert + 63; }
     const u64 h = splitmix64(S.seed ^ (L * 0xD1342543DE82EF95ull));
     const u64 h2 = splitmix64(h);
     const u64 g = h % S.cum[S.nchr];
     int c = 0;
     while (g >= S.cum[c + 1]) ++c;
     const u64 len = S.cum[c + 1] - S.cum[c];
-    const u64 span = len > (u64) S.read_len ? len - (u64) S.read_len + 1 : 1;
-    const u64 pos0 = h2 % span;
+    const u64 span = len > foot ? len - foot + 1 : 1;
+    const u64 pos0 = h2 % span + mate * ((u64) S.pair_insert + ((h >> 32) & 63ull));
     int4 a;
     a.x = (int) (pos0 + 1);
     a.y = a.x + S.read_len - 1;
-    a.z = (int) ((((u32) c + 1u) << 1) | (u32) ((h >> 63) & 1ull));
+    a.z = (int) ((((u32) c + 1u) << 1) | (u32) (((h >> 63) ^ mate) & 1ull));
     a.w = (int) (u32) qid;
     aln[j] = a;
     if (nhp) nhp[j] = nh;
@@ -1571,7 +1654,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
-  HIPCHK(hipMalloc((void **) &c->d_rowTot, 256 * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
+  HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 1) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
   HIPCHK(hipMalloc((void **) &c->d_seg, 2 * GT_CAP * 4));
   *out = c;
   return mm_reset(c);
@@ -1621,7 +1704,7 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_gpay, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
-    HIPCHK(hipMalloc((void **) &c->d_hist, 256 * nblk * 4));
+    HIPCHK(hipMalloc((void **) &c->d_hist, (size_t) RS_ROWS * nblk * 4));
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
@@ -1680,15 +1763,16 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
   hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
-  hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, 0, fixed_bits);
-  hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, 0, fixed_bits);
+  // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
+  hipLaunchKernelGGL(k_rs_scan_rows, dim3(rebase ? RS_ROW_COUNT + 1 : 256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, 0, fixed_bits);
+  hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, 0, fixed_bits, c->d_hist, nblk, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
                      fixed_bits, c->d_hist, c->d_rowTot, nblk);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int shift = 8; shift < max_bits; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
     hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, shift, fixed_bits);
-    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, shift, fixed_bits);
+    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, shift, fixed_bits, c->d_hist, nblk, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk);
     std::swap(kin, kout); std::swap(vin, vout);
@@ -1976,7 +2060,8 @@ extern "C" int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_p
   if (p->nh_max < 1 || p->nh_max > 4096 || p->read_len < 1) return fail(MM_ERR_ARG, "mm_synth_fill: bad nh_max/read_len");
   SynthDev S;
   S.seed = p->seed; S.first = p->first; S.read_len = p->read_len; S.nh_max = p->nh_max; S.nchr = p->n_chromosomes;
-  S.scatter_log2 = p->scatter_log2;
+  S.scatter_log2 = p->scatter_log2; S.pair_insert = p->pair_insert;
+  if (p->pair_insert && p->nh_max != 1) return fail(MM_ERR_ARG, "mm_synth_fill: pairs are generated with NH = 1 only");
   S.cum[0] = 0;
   for (int c = 0; c < p->n_chromosomes; ++c) {
     if (p->chr_len[c] < 1 || p->chr_len[c] > 0x7FFFFF00) return fail(MM_ERR_RANGE, "mm_synth_fill: chromosome length");

@@ -4,6 +4,9 @@
                      human-like lengths, ~60 k genes -> ~1.3 M intervals        (configs[2], [4])
     shape "tair10" : configTAIR10-shaped Order (14 elements / 13 lines), 5 chromosomes,
                      ~33 k genes -> ~0.45 M intervals                           (configs[1])
+    shape "flybase6": configFlybase6-shaped Order (16 elements / 15 lines: Introns + Vicinity of
+                     FlyBase:gene, a second source for piRNA), 8 chromosome arms,
+                     ~17 k genes -> ~0.2 M intervals                            (configs[3])
 
 A gene model is (chromosome, strand, merged exons, CDS hull).  From it the generator emits
   * the intervals the reference derives from such a gene (mmannot.cpp:1227-1266: CDS pieces, 5'UTR,
@@ -25,6 +28,7 @@ STRAND_ALL, STRAND_F, STRAND_R = 0, 1, 2
 _SMALL_HS = ["miRNA", "snoRNA", "snRNA", "lincRNA", "piRNA", "rRNA", "misc_RNA", "transcribed_processed_pseudogene",
              "processed_pseudogene", "polymorphic_pseudogene", "unprocessed_pseudogene", "pseudogene"]
 _SMALL_TAIR = ["miRNA", "tRNA", "snoRNA", "snRNA", "rRNA", "transposable_element_gene", "pseudogenic_transcript"]
+_SMALL_FLY = ["miRNA", "tRNA", "snoRNA", "snRNA", "rRNA", "ncRNA", "pre_miRNA"]
 
 
 def order_lines(shape: str) -> List[List[Tuple[str, str, int]]]:
@@ -42,6 +46,13 @@ def order_lines(shape: str) -> List[List[Tuple[str, str, int]]]:
         lines += [[(t, s, STRAND_ALL)] for s in _SMALL_TAIR]
         lines += [[(t, "gene", STRAND_R)], [(t, "intron", STRAND_ALL)], [(t, "upstream", STRAND_ALL), (t, "downstream", STRAND_ALL)]]
         return lines
+    if shape == "flybase6":
+        f = "FlyBase"
+        lines = [[(f, "CDS", STRAND_F)], [(f, "5'UTR", STRAND_F)], [(f, "3'UTR", STRAND_F)]]
+        lines += [[(f, s, STRAND_ALL)] for s in _SMALL_FLY]
+        lines += [[("piRNA", "piRNA", STRAND_ALL)], [(f, "pseudogene", STRAND_ALL)], [(f, "gene", STRAND_R)], [(f, "intron", STRAND_ALL)],
+                  [(f, "upstream", STRAND_ALL), (f, "downstream", STRAND_ALL)]]
+        return lines
     raise ValueError(shape)
 
 
@@ -56,7 +67,8 @@ def config_json(shape: str):
 def config_text(shape: str) -> str:
     """The same Order as a configuration *file* (Synonyms/Introns/Vicinity sections as the shape needs)."""
     lines = order_lines(shape)
-    main = [("protein_coding", "gene"), ("processed_transcript", "gene")] if shape == "hs38" else [("TAIR10", "gene")]
+    main = {"hs38": [("protein_coding", "gene"), ("processed_transcript", "gene")], "tair10": [("TAIR10", "gene")],
+            "flybase6": [("FlyBase", "gene")]}[shape]
     txt = ["Synonyms:", "mRNA:transcript", "five_prime_UTR:5'UTR", "three_prime_UTR:3'UTR", "Introns:"]
     txt += [f"{s}:{t}" for s, t in main] + ["Vicinity:"] + [f"{s}:{t}" for s, t in main] + ["Order:"]
     for line in lines:
@@ -68,6 +80,7 @@ HS38_CHR = [("1", 248.9), ("2", 242.2), ("3", 198.3), ("4", 190.2), ("5", 181.5)
             ("9", 138.4), ("10", 133.8), ("11", 135.1), ("12", 133.3), ("13", 114.4), ("14", 107.0), ("15", 102.0), ("16", 90.3),
             ("17", 83.3), ("18", 80.4), ("19", 58.6), ("20", 64.4), ("21", 46.7), ("22", 50.8), ("X", 156.0), ("Y", 57.2), ("MT", 0.0166)]
 TAIR10_CHR = [("1", 30.43), ("2", 19.70), ("3", 23.46), ("4", 18.59), ("5", 26.98)]
+FLY_CHR = [("2L", 23.51), ("2R", 25.29), ("3L", 28.11), ("3R", 32.08), ("4", 1.35), ("X", 23.54), ("Y", 3.67), ("mitochondrion_genome", 0.0195)]
 
 
 @dataclass
@@ -103,7 +116,7 @@ def synth_annotation(shape: str = "hs38", seed: int = 3, scale: float = 1.0, up:
                      keep_genes: bool = False) -> Annotation:
     rng = np.random.default_rng(seed)
     cfg = config_json(shape)
-    chrs = HS38_CHR if shape == "hs38" else TAIR10_CHR
+    chrs = {"hs38": HS38_CHR, "tair10": TAIR10_CHR, "flybase6": FLY_CHR}[shape]
     names = [c for c, _ in chrs]
     clen = np.array([int(m * 1e6) for _, m in chrs], dtype=np.int64)
     total = clen.sum()
@@ -112,10 +125,15 @@ def synth_annotation(shape: str = "hs38", seed: int = 3, scale: float = 1.0, up:
                 ("processed_transcript", "gene", int(14000 * scale), False, 3.5, 180, 0.6, 2500, 1.4)]
         small = [(s, "gene", int(n * scale)) for s, n in zip(_SMALL_HS, [1900, 950, 1900, 7500, 120, 550, 2200, 500, 10200, 60, 2600, 300])]
         small_len = (60, 2000)
-    else:
+    elif shape == "tair10":
         main = [("TAIR10", "gene", int(27400 * scale), True, 5.6, 170, 0.6, 120, 0.75)]
         small = [("TAIR10", s, int(n * scale)) for s, n in zip(_SMALL_TAIR, [180, 690, 71, 13, 15, 3900, 920])]
         small_len = (60, 4000)
+    else:
+        main = [("FlyBase", "gene", int(13900 * scale), True, 4.0, 250, 0.8, 100, 1.5)]
+        small = [("FlyBase", s, int(n * scale)) for s, n in zip(_SMALL_FLY, [480, 310, 290, 30, 110, 2500, 260])]
+        small += [("piRNA", "piRNA", int(400 * scale)), ("FlyBase", "pseudogene", int(330 * scale))]
+        small_len = (60, 3000)
     vic = {s for s, t, *_ in main}
     out_chr, out_s, out_e, out_t, out_sd = [], [], [], [], []
     genes = []

@@ -23,9 +23,12 @@ GOLD = os.path.join(ROOT, "tests", "golden", "synth_e2e")
 WORKLOADS = {
     "tair10": dict(shape="tair10", seed=5, scale=0.02, n=60000, read_len=50, nh_max=6, scatter=8, rseed=11),
     "hs38": dict(shape="hs38", seed=6, scale=0.01, n=80000, read_len=100, nh_max=20, scatter=12, rseed=12),
+    # BASELINE.json configs[3]: read pairs (mates share a name) against a Flybase6-shaped annotation with introns + vicinity
+    "flybase6": dict(shape="flybase6", seed=7, scale=0.05, n=60000, read_len=100, nh_max=1, scatter=0, rseed=13, pair=250),
 }
 RUNS = [["-s", "F"], ["-s", "R", "-l", "0.5"], ["-s", "U", "-y", "unique"], ["-s", "F", "-y", "ratio"], ["-s", "F", "-l", "30", "-d", "300", "-D", "50"],
-        ["-s", "R", "-y", "ratio", "-l", "1"], ["-s", "F", "-M", "$MM"], ["-s", "U", "-y", "random"], ["-s", "F", "-l", "0.3", "-m", "$M", "-M", "$MM", "-e", "60"]]
+        ["-s", "R", "-y", "ratio", "-l", "1"], ["-s", "F", "-M", "$MM"], ["-s", "U", "-y", "random"], ["-s", "F", "-l", "0.3", "-m", "$M", "-M", "$MM", "-e", "60"],
+        ["-s", "U", "-l", "50", "-d", "1000", "-D", "1000"]]
 
 
 def make_inputs(w, d):
@@ -39,7 +42,7 @@ def make_inputs(w, d):
     span = np.zeros(an.n_chromosomes, dtype=np.int64)
     np.maximum.at(span, an.chr, an.end + 2000)
     span = np.maximum(span, 10000)
-    t = sr.synth_tuples(w["rseed"], 0, w["n"], w["read_len"], w["nh_max"], span, w["scatter"])
+    t = sr.synth_tuples(w["rseed"], 0, w["n"], w["read_len"], w["nh_max"], span, w["scatter"], w.get("pair", 0))
     flag = np.where(t["strand"] == 1, 0, 16).astype(np.uint16)
     body = mo.bam_records_fixed(t["tid"], t["start"] - 1, flag, t["qid"], np.full(w["n"], w["read_len"]), t["nh"] if w["nh_max"] > 1 else None)
     bam = os.path.join(d, "r.bam")

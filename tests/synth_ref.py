@@ -43,13 +43,14 @@ def random_index(rng, E, nchr=3, n=2000, maxpos=200000, long_frac=0.05, skip_chr
 
 
 def random_reads(rng, index, n=5000, nchr=3, maxpos=200000, nh_max=6, zero_len_frac=0.03, unknown_frac=0.02,
-                 malformed_groups=True):
-    """Reads grouped by name; a share of the groups is over-/under-complete or mixes NH values."""
+                 malformed_groups=True, shuffle=True, nh_min=1):
+    """Reads grouped by name; a share of the groups is over-/under-complete or mixes NH values.  shuffle=False keeps the
+    hits of a read adjacent (an aligner's own output order)."""
     tid, start, end, strand, nh, qid = [], [], [], [], [], []
     q = 0
     ends = index["end"]
     while len(start) < n:
-        k = int(rng.integers(1, nh_max + 1))
+        k = int(rng.integers(nh_min, nh_max + 1))
         recs = k
         nhs = [k] * k
         if malformed_groups and k > 1:
@@ -85,7 +86,7 @@ def random_reads(rng, index, n=5000, nchr=3, maxpos=200000, nh_max=6, zero_len_f
     a = dict(tid=np.array(tid, dtype=np.int32), start=np.array(start, dtype=np.int64), end=np.array(end, dtype=np.int64),
              strand=np.array(strand, dtype=np.uint8), nh=np.array(nh, dtype=np.uint32), qid=np.array(qid, dtype=np.int64))
     # interleave: the hits of one read are generally not adjacent in a coordinate-sorted file
-    perm = np.argsort(rng.random(len(a["start"])) + np.arange(len(a["start"])) / 40.0, kind="stable")
+    perm = np.argsort(rng.random(len(a["start"])) + np.arange(len(a["start"])) / 40.0, kind="stable") if shuffle else np.arange(len(a["start"]))
     return {k: v[perm][:n] for k, v in a.items()}
 
 
@@ -99,7 +100,7 @@ def splitmix64(x):
         return z ^ (z >> np.uint64(31))
 
 
-def synth_tuples(seed, first, n, read_len, nh_max, chr_len, scatter_log2):
+def synth_tuples(seed, first, n, read_len, nh_max, chr_len, scatter_log2, pair_insert=0):
     """Exactly what mm_synth_fill writes (mm_device.hip:k_synth)."""
     with np.errstate(over="ignore"):
         i = np.uint64(first) + np.arange(n, dtype=np.uint64)
@@ -118,15 +119,20 @@ def synth_tuples(seed, first, n, read_len, nh_max, chr_len, scatter_log2):
             k = np.where((k + np.uint64(1)) * (k + np.uint64(2)) // np.uint64(2) <= off, k + np.uint64(1), k)
             nh = (k + np.uint64(1)).astype(np.uint32)
             qid = blk * K + k
+        mate = np.zeros(n, dtype=np.uint64)
+        foot = np.uint64(read_len)
+        if pair_insert:
+            assert nh_max == 1
+            mate = L & np.uint64(1); L = L >> np.uint64(1); qid = L.copy(); foot = np.uint64(read_len + pair_insert + 63)
         h = splitmix64(np.uint64(seed) ^ (L * np.uint64(0xD1342543DE82EF95)))
         h2 = splitmix64(h)
         cum = np.concatenate([[0], np.cumsum(np.asarray(chr_len, dtype=np.uint64))]).astype(np.uint64)
         g = h % cum[-1]
         c = np.searchsorted(cum, g, side="right") - 1
         ln = cum[c + 1] - cum[c]
-        span = np.where(ln > np.uint64(read_len), ln - np.uint64(read_len) + np.uint64(1), np.uint64(1))
-        pos0 = h2 % span
+        span = np.where(ln > foot, ln - foot + np.uint64(1), np.uint64(1))
+        pos0 = h2 % span + mate * (np.uint64(pair_insert) + ((h >> np.uint64(32)) & np.uint64(63)))
         start = (pos0 + np.uint64(1)).astype(np.int64)
         end = start + read_len - 1
-        strand = ((h >> np.uint64(63)) & np.uint64(1)).astype(np.uint8)
+        strand = (((h >> np.uint64(63)) ^ mate) & np.uint64(1)).astype(np.uint8)
     return dict(tid=c.astype(np.int32), start=start, end=end, strand=strand, nh=nh, qid=(qid & np.uint64(0xFFFFFFFF)).astype(np.int64))

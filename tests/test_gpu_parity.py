@@ -90,6 +90,55 @@ def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
             assert got == want
 
 
+def test_name_grouped_input(gpu_lib, oracle):
+    """An aligner's own output keeps the hits of a read adjacent, so read-name ids are non-decreasing and the name sort is
+    skipped (k_rs_hist's order check).  Same answers as the oracle, malformed groups included; and one inversion anywhere -
+    inside a wave, or across the wave (64) / round (256) / tile (4096) boundaries of the check - must send the batch down
+    the general path and still give the oracle's answer."""
+    mm = gpu_lib
+    rng = np.random.default_rng(99)
+    desc = sr.random_config(rng, n_lines=6, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=2500, maxpos=120000)
+    cfg = to_cfg(mm, desc)
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], ix["n_chromosomes"])
+
+    def gpu(reads, batches):
+        ctr = mm.Counter(index, overlap=-1.0, strandedness="U", strategy="default")
+        aln = mm.pack_alignments(reads["tid"], reads["start"], reads["end"], reads["strand"], reads["qid"])
+        cuts = np.linspace(0, len(aln), batches + 1).astype(int)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctr.add_batch(aln[a:b], reads["nh"][a:b].astype(np.uint32), int(reads["qid"].max()) + 1)
+        ctr.flush()
+        masks, sums = ctr.getCounts()
+        out = (dict(zip(masks.tolist(), sums.tolist())), ctr.stats(), ctr.grouped_batches())
+        ctr.close()
+        return out
+
+    for nh_min in (1, 2):
+        reads = sr.random_reads(rng, ix, n=21000, nchr=3, maxpos=120000, nh_max=7, shuffle=False, nh_min=nh_min)
+        assert (np.diff(reads["qid"]) >= 0).all()
+        ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="U", strategy="default")
+        for batches in (1, 4):
+            rows, st, grouped = gpu(reads, batches)
+            assert st == ref.stats and rows == dict(zip(ref.row_mask.tolist(), ref.row_count.astype(float).tolist()))
+            assert grouped == batches
+        q, nh = reads["qid"], reads["nh"]
+        for pos in (1, 37, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8191, 8192, 12288, 20990):
+            j = pos
+            while j < len(q) and not (q[j] != q[j - 1] and nh[j] != 1 and nh[j - 1] != 1):
+                j += 1
+            if j >= len(q):
+                continue
+            r2 = {k: v.copy() for k, v in reads.items()}
+            for v in r2.values():
+                v[[j - 1, j]] = v[[j, j - 1]]
+            ref2 = oracle.run(desc, ix, r2, overlap=-1.0, strandedness="U", strategy="default")
+            rows, st, grouped = gpu(r2, 1)
+            assert grouped == 0, pos
+            assert st == ref2.stats and rows == dict(zip(ref2.row_mask.tolist(), ref2.row_count.astype(float).tolist())), pos
+    index.close()
+
+
 def test_empty_and_edge_batches(gpu_lib, oracle):
     mm = gpu_lib
     rng = np.random.default_rng(77)
@@ -125,15 +174,15 @@ def test_synth_generator_twin(gpu_lib):
     mm = gpu_lib
     from mmannot_amd import _lib
     chr_len = np.array([30_000_000, 19_000_000, 23_000_000, 18_000_000, 27_000_000], dtype=np.int64)
-    for nh_max, sc, first in ((1, 0, 0), (20, 0, 12345), (20, 10, 1 << 20), (5, 16, 777)):
+    for nh_max, sc, first, pair in ((1, 0, 0, 0), (20, 0, 12345, 0), (20, 10, 1 << 20, 0), (5, 16, 777, 0), (1, 0, 4321, 250)):
         n = 100_000
         aln = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
         nh = torch.zeros(n, dtype=torch.int32, device="cuda")
-        p = _lib.SynthParams(42, first, 100, nh_max, len(chr_len), chr_len.ctypes.data, sc)
+        p = _lib.SynthParams(42, first, 100, nh_max, len(chr_len), chr_len.ctypes.data, sc, pair)
         _lib.check(_lib.lib().mm_synth_fill(aln.data_ptr(), nh.data_ptr(), n, C.byref(p), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         a = aln.cpu().numpy().view(np.uint32)
-        t = sr.synth_tuples(42, first, n, 100, nh_max, chr_len, sc)
+        t = sr.synth_tuples(42, first, n, 100, nh_max, chr_len, sc, pair)
         assert (a[:, 0].astype(np.int64) == t["start"]).all() and (a[:, 1].astype(np.int64) == t["end"]).all()
         assert ((a[:, 2] >> 1).astype(np.int64) - 1 == t["tid"]).all() and ((a[:, 2] & 1) == t["strand"]).all()
         assert (a[:, 3].astype(np.int64) == t["qid"]).all()
