@@ -100,10 +100,11 @@ SYMBOLS = {
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m mmannot_amd.build` "
+        path = os.environ.get("MMANNOT_AMD_LIB", LIB_PATH)   # another build of the same library (kernel experiments)
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python -m mmannot_amd.build` "
                               "(the HIP library is the only implementation of the hot path; there is no fallback)")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             if not hasattr(l, name):
                 continue  # optional groups are bound lazily below

@@ -66,7 +66,12 @@ extern "C" const char *mm_version(void) { return MM_VERSION; }
 #define LT_CAP 1024u               // per-workgroup LDS table
 #define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
-#define MM_LDS_CHR 512               // chromosome tables up to this size are staged in LDS by k_probe
+#define MM_LDS_CHR 256               // chromosome tables up to this size are staged in LDS by k_probe
+// k_probe is a chain of dependent gathers (tuple -> slot line -> rest of the line), i.e. latency bound: it runs at the
+// hardware's maximum of 8 waves per SIMD (<= 64 VGPRs, < 20 KB LDS per 256 threads).  Measured on MI355X against the
+// compiler's own choice of 73 VGPRs / 6 waves: -9 % (c3), -20 % (c2), -18 % (c4, where the -l arithmetic then spills
+// 88 B per lane to scratch and is still faster).  Prefetching the next tuple instead did not help.
+#define MM_PROBE_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 
 // per-batch scalars kept on the device (no host round trip between the kernels of one batch)
 enum { INFO_M = 0,      // number of records in the grouping pipeline
@@ -493,7 +498,7 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
 //     ordered -y ratio accumulation, or
 //   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
 template <int OVL>
-__global__ __launch_bounds__(256) void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const u32 *__restrict__ nhp,
+__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const u32 *__restrict__ nhp,
                                                size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
                                                u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
                                                u64 *__restrict__ walkstat) {
