@@ -641,46 +641,48 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   __shared__ u32 tileCnt, tileBad;
   if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
   const bool order = FIRST && rebase;
+  // (the check stops at the first inversion: this wave's, or one another tile has already published)
+  bool chk = order && ((volatile u32 *) info)[INFO_UNSORTED] == 0;
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   h[threadIdx.x] = 0;
-  if (threadIdx.x == 0) { tileCnt = 0; tileBad = 0; }
+  if (threadIdx.x == 0) { tileCnt = 0; tileBad = chk ? 0u : 1u; }
   __syncthreads();
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
-  u32 bad = 0, wcnt = 0;
+  u32 wcnt = 0;
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
     u32 k = 0, v;
     const bool ok = rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v);
     if (ok) atomicAdd(&h[(k >> shift) & 255u], 1u);
-    if (order) {
+    if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
       const u64 below = vm & ((1ull << lane) - 1ull);
       const u32 pk = __shfl(k, below ? 63 - __clzll((long long) below) : 0);
-      if (ok && below && pk > k) bad = 1;
       const u32 kf = __shfl(k, vm ? __ffsll((long long) vm) - 1 : 0), kl = __shfl(k, vm ? 63 - __clzll((long long) vm) : 0);
       if (lane == 0) { segF[r * 4 + w] = vm ? kf : NO_KEY; segL[r * 4 + w] = vm ? kl : NO_KEY; wcnt += (u32) __popcll(vm); }
+      if (__ballot(ok && below && pk > k)) { chk = false; if (lane == 0) tileBad = 1; }
     }
   }
-  if (order && lane == 0) atomicAdd(&tileCnt, wcnt);
-  if (order && __ballot(bad) && lane == 0) tileBad = 1;
+  if (chk && lane == 0) atomicAdd(&tileCnt, wcnt);
   __syncthreads();
   hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
-  if (order && w == 0) {   // the tile's 64 segments in file order (segment = round * 4 + wave), one per lane
+  if (order && w == 0 && tileBad == 0) {   // the tile's 64 segments in file order (segment = round * 4 + wave), one per lane
     const u32 F = segF[lane], L = segL[lane];
     const bool has = F != NO_KEY;
     const u64 vm = __ballot(has);
     const u64 below = vm & ((1ull << lane) - 1ull);
     const u32 pl = __shfl(L, below ? 63 - __clzll((long long) below) : 0);
-    if (__ballot(has && below && pl > F)) bad = 1;   // wave-wide, so that thread 0 knows
+    const bool sbad = __ballot(has && below && pl > F) != 0;
     const u32 tf = __shfl(F, vm ? __ffsll((long long) vm) - 1 : 0), tl = __shfl(L, vm ? 63 - __clzll((long long) vm) : 0);
     if (lane == 0) {
       hist[(size_t) RS_ROW_COUNT * nblk + blockIdx.x] = tileCnt;
       hist[(size_t) RS_ROW_FIRST * nblk + blockIdx.x] = vm ? tf : NO_KEY;
       hist[(size_t) RS_ROW_LAST * nblk + blockIdx.x] = vm ? tl : NO_KEY;
+      if (sbad) tileBad = 1;
     }
   }
   // one flag for the whole batch: on unsorted input nearly every tile finds an inversion, so look before the atomic
-  if (order && threadIdx.x == 0 && (tileBad || bad) && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
+  if (order && threadIdx.x == 0 && tileBad && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
 }
 
 // one workgroup per digit: exclusive scan of its row of per-tile counts
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal,
   __shared__ u32 s[256];
   __shared__ u32 wmax[4];
   if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
-  if (order) {   // between tiles: a tile's first key may not be below the largest last key of the tiles before it
+  if (order && info[INFO_UNSORTED] == 0) {   // between tiles: a tile's first key may not be below the largest last key of the tiles before it
     const u32 *first = hist + (size_t) RS_ROW_FIRST * nblk, *last = hist + (size_t) RS_ROW_LAST * nblk;
     const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 carry = 0, bad = 0;
