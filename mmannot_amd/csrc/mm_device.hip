@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
 // First pass (FIRST = true) reads the batch's records where k_probe left them: key gkey[i] (NO_KEY = not in the
 // grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
 // payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
-// in file order within each digit, and k_rs_scan_tot publishes their number (INFO_M) for the following passes.
+// in file order within each digit, and k_rs_scan publishes their number (INFO_M) for the following passes.
 template <bool FIRST>
 __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *__restrict__ vin, const u32 *__restrict__ info, size_t i, size_t n,
                                         int rebase, u32 &k, u32 &v) {
@@ -631,7 +631,7 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
 // Order check (first pass of the name sort only): an aligner writes the hits of one read one after the other, and read-name
 // ids are handed out in order of first appearance, so the qids of such a file are already non-decreasing and the "sort"
 // only has to compact.  Every record is compared with the nearest earlier record of the pipeline: inside a wave by ballot,
-// between the 64 wave-segments of a tile through LDS, between tiles by k_rs_scan_tot.  Any inversion sets INFO_UNSORTED
+// between the 64 wave-segments of a tile through LDS, between tiles by k_rs_scan.  Any inversion sets INFO_UNSORTED
 // and the batch takes the general path.
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ info,
@@ -685,46 +685,56 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   if (order && threadIdx.x == 0 && tileBad && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
 }
 
-// one workgroup per digit: exclusive scan of its row of per-tile counts
-__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal,
-                                                      const u32 *__restrict__ info, int shift, int fixed_bits) {
+// One workgroup per digit: exclusive scan of its row of per-tile counts.  The workgroup that finishes last then turns the
+// row totals into the digits' global bases (and, for the first pass of the name sort, finishes the order check between
+// tiles and publishes the number of pairs) - one launch instead of two on a path made of short kernels.
+__global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal, u32 *__restrict__ done,
+                                                 u32 *__restrict__ info, int shift, int fixed_bits, int order, u64 *__restrict__ walkstat) {
   __shared__ u32 wsum[4];
   __shared__ u32 carry;
+  __shared__ u32 isLast;
   if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
   u32 *row = hist + (size_t) blockIdx.x * nblk;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (u32 base = 0; base < nblk; base += 256) {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < nblk) ? row[i] : 0;
-    u32 x = v;
+  // every thread owns 16 consecutive tiles: all its loads are in flight together, then local scan -> wave -> workgroup
+  for (u32 base = 0; base < nblk; base += 256 * 16) {
+    const u32 i0 = base + threadIdx.x * 16;
+    u32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const u32 t = v[k]; v[k] = tot; tot += t; }
+    u32 x = tot;
     for (int off = 1; off < 64; off <<= 1) {
       const u32 y = __shfl_up(x, off);
       if ((int) lane >= off) x += y;
     }
     if (lane == 63) wsum[w] = x;
     __syncthreads();
-    u32 woff = 0;
+    u32 woff = carry;
     for (u32 k = 0; k < w; ++k) woff += wsum[k];
-    const u32 c = carry;
-    if (i < nblk) row[i] = c + woff + x - v;
+    const u32 pre = woff + x - tot;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (i0 + k < nblk) row[i0 + k] = pre + v[k];
     __syncthreads();
-    if (threadIdx.x == 255) carry = c + woff + x;
+    if (threadIdx.x == 255) carry = pre + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
-}
-
-__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal, u32 *__restrict__ info, int shift, int fixed_bits,
-                                                     const u32 *__restrict__ hist, u32 nblk, int order, u64 *__restrict__ walkstat) {
-  __shared__ u32 s[256];
-  __shared__ u32 wmax[4];
-  if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
-  if (order && info[INFO_UNSORTED] == 0) {   // between tiles: a tile's first key may not be below the largest last key of the tiles before it
+  if (threadIdx.x == 0) {
+    rowTotal[blockIdx.x] = carry;
+    __threadfence();
+    isLast = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!isLast) return;
+  __threadfence();
+  if (threadIdx.x == 0) *done = 0;   // ready for the next pass
+  if (order && ((volatile u32 *) info)[INFO_UNSORTED] == 0) {   // between tiles: a tile's first key may not be below the largest last key before it
     const u32 *first = hist + (size_t) RS_ROW_FIRST * nblk, *last = hist + (size_t) RS_ROW_LAST * nblk;
-    const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 carry = 0, bad = 0;
+    u32 cmax = 0, bad = 0;
     for (u32 base = 0; base < nblk; base += 256) {
       const u32 i = base + threadIdx.x;
       const u32 F = i < nblk ? first[i] : NO_KEY;
@@ -734,28 +744,37 @@ __global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *__restrict__ rowTotal,
         const u32 y = __shfl_up(x, off);
         if ((int) lane >= off) x = max(x, y);
       }
-      if (lane == 63) wmax[w] = x;
+      if (lane == 63) wsum[w] = x;
       __syncthreads();
-      u32 before = carry, all = carry;
-      for (u32 q = 0; q < 4; ++q) { if (q < w) before = max(before, wmax[q]); all = max(all, wmax[q]); }
+      u32 before = cmax, all = cmax;
+      for (u32 q = 0; q < 4; ++q) { if (q < w) before = max(before, wsum[q]); all = max(all, wsum[q]); }
       const u32 prev = __shfl_up(x, 1);
       if (lane > 0) before = max(before, prev);
       if (F != NO_KEY && F < before) bad = 1;
-      carry = all;
+      cmax = all;
       __syncthreads();
     }
     if (bad) atomicOr(&info[INFO_UNSORTED], 1u);
   }
-  s[threadIdx.x] = rowTotal[threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 acc = 0;
-    for (int d = 0; d < 256; ++d) { const u32 v = s[d]; s[d] = acc; acc += v; }
-    if (shift == 0) info[INFO_M] = acc;   // the first pass compacts: this is the number of pairs in the pipeline
-    if (order && acc && !info[INFO_UNSORTED]) atomicAdd(&walkstat[1], 1ull);   // (reported by mm_get_walk_stats)
+  {  // exclusive scan of the 256 row totals
+    const u32 v = ((volatile u32 *) rowTotal)[threadIdx.x];
+    u32 x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if ((int) lane >= off) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 k = 0; k < w; ++k) woff += wsum[k];
+    rowTotal[threadIdx.x] = woff + x - v;
+    if (threadIdx.x == 255) {
+      const u32 acc = woff + x;
+      if (shift == 0) info[INFO_M] = acc;   // the first pass compacts: this is the number of pairs in the pipeline
+      if (order && acc && !((volatile u32 *) info)[INFO_UNSORTED]) atomicAdd(&walkstat[1], 1ull);   // (reported by mm_get_walk_stats)
+    }
   }
-  __syncthreads();
-  rowTotal[threadIdx.x] = s[threadIdx.x];
 }
 
 // One pass of the stable LSD sort for one tile of RS_TILE pairs.
@@ -854,9 +873,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
 __global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ kA, const u32 *__restrict__ vA, const u32 *__restrict__ kB,
                                                        const u32 *__restrict__ vB, const u32 *__restrict__ info,
                                                        const u32 *__restrict__ nhp, const u64 *__restrict__ hm, u32 *__restrict__ grpRem,
-                                                       u64 *__restrict__ grpU, u64 qcap, GlobalTable G, u64 *__restrict__ stats) {
+                                                       u64 *__restrict__ grpU, u64 qcap, GlobalTable G, u64 *__restrict__ stats, int nelem) {
   __shared__ LdsTable T;
   __shared__ u32 sOpened, sRescued;
+  __shared__ u32 sKey[256 + 64], sNh[256 + 64];   // this round's records and the 64 behind them
+  __shared__ u64 sM[256 + 64];
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
   if (info[INFO_M] != 0 && (u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicExch(G.err, 2u); return; }
   lds_table_init(T);
@@ -870,69 +891,123 @@ __global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ k
   const u32 *__restrict__ svals = (passes & 1) ? vB : vA;
   const u32 lane = threadIdx.x & 63;
   u32 opened = 0, rescued = 0;
-  // record k of the sorted stream -> (element set, NH)
-  auto fetch = [&](size_t k, u64 &m, u32 &nhv) __attribute__((always_inline)) {
-    const u32 pv = svals[k];
+  // payload of a record of the sorted stream -> (element set, NH)
+  auto decode = [&](u32 pv, u64 &m, u32 &nhv) __attribute__((always_inline)) {
     if (by_index) { m = hm[pv]; nhv = nhp[pv]; }
     else { const u32 slot = pv & 0xFFFFu; m = (slot == 0xFFFFu) ? 0ull : G.key[slot]; nhv = pv >> 16; }
   };
+  auto fetch = [&](size_t k, u64 &m, u32 &nhv) __attribute__((always_inline)) { decode(svals[k], m, nhv); };
   auto close_group = [&](u64 U) __attribute__((always_inline)) {
     if (U) {
       count_set(T, G, U);
       if ((U & (U - 1)) == 0) ++rescued;
     }
   };
-  const size_t Mr = ((size_t) M + 63) & ~(size_t) 63;
-  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < Mr; j += (size_t) gridDim.x * blockDim.x) {
-    // every lane loads its own record and both neighbours' keys (coalesced); a name's records are consecutive
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  const u32 w = threadIdx.x >> 6;
+  // The kernel is a chain of dependent gathers (key -> per-name state; payload -> element set): each round requests the
+  // next round's records - its own, and the first wave also the 64 behind the workgroup's 256 - before it works on its own.
+  // (A name has one head record per batch, so its state is read and written by exactly one lane: reading it early is safe.)
+  u32 nKey = 0, nPrev = 0, nNext = 0, nNh = 0, nRem = 0, nHk = NO_KEY, nHn = 0;
+  u64 nM = 0, nU = 0, nHm = 0;
+  auto preload = [&](size_t b) __attribute__((always_inline)) {
+    const size_t j = b + w * 64 + (63 - lane);
+    nKey = 0; nNh = 0; nM = 0; nPrev = 0; nNext = 0;
+    if (j < M) {
+      nKey = skeys[j];
+      nPrev = j ? skeys[j - 1] : ~nKey;
+      nNext = (j + 1 < M) ? skeys[j + 1] : ~nKey;
+      if (nPrev != nKey) { nRem = grpRem[nKey + qmin]; nU = grpU[nKey + qmin]; }
+      fetch(j, nM, nNh);
+    }
+    if (threadIdx.x < 64) {
+      const size_t jh = b + 256 + threadIdx.x;
+      nHk = NO_KEY; nHn = 0; nHm = 0;
+      if (jh < M) { nHk = skeys[jh]; fetch(jh, nHm, nHn); }
+    }
+  };
+  preload((size_t) blockIdx.x * blockDim.x);
+  for (size_t base = (size_t) blockIdx.x * blockDim.x; base < M; base += stride) {   // (workgroup-uniform trip count)
+    // Every lane loads its own record and both neighbours' keys; a name's records are consecutive.  Lanes take the
+    // wave's 64 records in REVERSE order (lane 63 = the earliest record): the per-name reduction then runs towards
+    // higher lanes, which is the direction the DPP row-shift / row-broadcast network moves data in.
+    // The workgroup's 256 records plus the 64 that follow them are also staged in LDS: a name that runs past the end
+    // of its wave is completed from there instead of through another round of dependent global loads.
+    const u32 pos = w * 64 + (63 - lane);                 // position inside the workgroup's 256 records
+    const size_t j = base + pos;
     const bool valid = j < M;
-    u32 key = 0, nhv = 0, rem = 0;
-    u64 m = 0, U = 0;
-    bool head = false, last = true;
-    if (valid) {
-      key = skeys[j];
-      head = (j == 0) || (skeys[j - 1] != key);
-      last = (j + 1 >= M) || (skeys[j + 1] != key);
-      if (head) { rem = grpRem[key + qmin]; U = grpU[key + qmin]; }   // issued early: independent of the set gather below
-      fetch(j, m, nhv);
+    // this round's record was requested during the previous round (see preload)
+    const u32 key = nKey, nhv = nNh;
+    const u64 m = nM;
+    const bool head = valid && nPrev != key, last = !valid || nNext != key;
+    u32 rem = head ? nRem : 0u;
+    u64 U = head ? nU : 0ull;
+    const u32 hk = nHk, hn = nHn;
+    const u64 hmk = nHm;
+    preload(base + stride);
+    sKey[pos] = valid ? key : NO_KEY; sM[pos] = m; sNh[pos] = nhv;
+    if (threadIdx.x < 64) { sKey[256 + threadIdx.x] = hk; sM[256 + threadIdx.x] = hmk; sNh[256 + threadIdx.x] = hn; }
+    __syncthreads();
+    // Segmented inclusive scan towards the head lane (a name's last record starts a segment): union of the sets,
+    // record count, min / max NH.  Kogge-Stone inside the rows of 16 lanes, then the two row broadcasts - all DPP moves
+    // on the vector ALU.  (The same reduction written with __shfl_down costs ~36 LDS-crossbar operations per round,
+    // and SQ_WAIT_INST_LDS showed this kernel waiting on exactly those.)
+    u32 ulo = (u32) m, uhi = (u32) (m >> 32), tcnt = valid ? 1u : 0u, tmin = valid ? nhv : 0xFFFFFFFFu, tmax = valid ? nhv : 0u;
+    u32 f = (last || lane == 0) ? 1u : 0u;
+#define MM_DPP(OLD, SRC, CTRL, RMASK) ((u32) __builtin_amdgcn_update_dpp((int) (OLD), (int) (SRC), (CTRL), (RMASK), 0xF, false))
+#define MM_SEG_STEP(CTRL, RMASK)                                                                               \
+    {                                                                                                          \
+      const u32 sf = MM_DPP(f, f, CTRL, RMASK); /* a lane without a source keeps its own flag and gets identities */ \
+      const u32 a0 = MM_DPP(0u, ulo, CTRL, RMASK), a1 = MM_DPP(0u, uhi, CTRL, RMASK), ac = MM_DPP(0u, tcnt, CTRL, RMASK); \
+      const u32 an = MM_DPP(0xFFFFFFFFu, tmin, CTRL, RMASK), ax = MM_DPP(0u, tmax, CTRL, RMASK);               \
+      if (!f) { ulo |= a0; uhi |= a1; tcnt += ac; tmin = min(tmin, an); tmax = max(tmax, ax); f = sf; }        \
     }
-    // segmented reduction towards the head lane over the part of the name that lies inside this wave:
-    // union of the sets, record count, min/max NH
-    bool stop = (lane == 63) || last;
-    u64 tU = m;
-    u32 tcnt = valid ? 1u : 0u, tmin = nhv, tmax = nhv;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u64 oU = __shfl_down(tU, d);
-      const u32 ocnt = __shfl_down(tcnt, d), omin = __shfl_down(tmin, d), omax = __shfl_down(tmax, d);
-      const bool ostop = __shfl_down((int) stop, d) != 0;
-      if (!stop && lane + d < 64) { tU |= oU; tcnt += ocnt; tmin = min(tmin, omin); tmax = max(tmax, omax); stop = ostop; }
-    }
-    // Does the wave's last name continue behind the wave?  Then the whole wave fetches the following records
-    // together (coalesced) and reduces the matching prefix, instead of one lane walking them one by one.
-    const bool spill = __shfl((int) (!last), 63) != 0;   // wave-uniform
+    MM_SEG_STEP(0x111, 0xF) MM_SEG_STEP(0x112, 0xF) MM_SEG_STEP(0x114, 0xF) MM_SEG_STEP(0x118, 0xF)   // row_shr:1,2,4,8
+    MM_SEG_STEP(0x142, 0xA)                                                                            // row_bcast:15 -> rows 1, 3
+    MM_SEG_STEP(0x143, 0xC)                                                                            // row_bcast:31 -> rows 2, 3
+#undef MM_SEG_STEP
+    u64 tU = ((u64) uhi << 32) | ulo;
+    // Does the wave's last name (at lane 0) continue behind the wave?  Then the whole wave looks at the following
+    // records together and the matching prefix joins that name's head lane - if its head is in this wave at all.
+    const u64 heads = __ballot(head);
+    const bool spill = (__ballot(valid && !last) & 1ull) != 0 && heads != 0;   // wave-uniform
     if (spill) {
-      const u32 skey = __shfl(key, 63);
-      size_t nb = (j | 63) + 1;
+      const int hl = __ffsll((long long) heads) - 1;                      // head lane of the name that reaches lane 0
+      const u32 skey = (u32) __builtin_amdgcn_readlane((int) key, 0);
       u64 xU = 0;
       u32 xcnt = 0, xmin = 0xFFFFFFFFu, xmax = 0;
-      for (;;) {
-        const size_t k = nb + lane;
-        const bool match = k < M && skeys[k] == skey;
-        const u64 mm = __ballot(match);
-        const u32 f = (~mm == 0ull) ? 64u : (u32) (__ffsll((long long) ~mm) - 1);   // length of the matching prefix
-        u64 m2 = 0; u32 n2lo = 0xFFFFFFFFu, n2hi = 0;
-        if (lane < f) { u32 n2; fetch(k, m2, n2); n2lo = n2; n2hi = n2; }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-          m2 |= __shfl_xor(m2, d); n2lo = min(n2lo, __shfl_xor(n2lo, d)); n2hi = max(n2hi, __shfl_xor(n2hi, d));
+      size_t nb = base + (size_t) (w + 1) * 64;
+      for (int step = 0;; ++step) {
+        u32 x0 = 0, x1 = 0, xn = 0xFFFFFFFFu, xx = 0;
+        bool match;
+        if (step == 0) {   // the 64 records behind this wave: from LDS (NO_KEY marks the end of the batch)
+          const u32 li = (w + 1) * 64 + lane;
+          match = sKey[li] == skey;
+          if (match) { const u64 mv = sM[li]; x0 = (u32) mv; x1 = (u32) (mv >> 32); xn = xx = sNh[li]; }
+        } else {
+          const size_t k = nb + lane;
+          match = k < M && skeys[k] == skey;
+          if (match) { u64 mv; u32 n2; fetch(k, mv, n2); x0 = (u32) mv; x1 = (u32) (mv >> 32); xn = xx = n2; }
         }
-        xU |= m2; xcnt += f; xmin = min(xmin, n2lo); xmax = max(xmax, n2hi);
-        if (f < 64) break;
+        const u64 mm = __ballot(match);
+        const u32 fl = (~mm == 0ull) ? 64u : (u32) (__ffsll((long long) ~mm) - 1);   // length of the matching prefix
+        if (lane >= fl) { x0 = 0; x1 = 0; xn = 0xFFFFFFFFu; xx = 0; }                  // (a later record of the same key cannot exist, but stay exact)
+#define MM_RED_STEP(CTRL, RMASK)                                                                     \
+        { x0 |= MM_DPP(0u, x0, CTRL, RMASK); x1 |= MM_DPP(0u, x1, CTRL, RMASK);                      \
+          xn = min(xn, MM_DPP(0xFFFFFFFFu, xn, CTRL, RMASK)); xx = max(xx, MM_DPP(0u, xx, CTRL, RMASK)); }
+        MM_RED_STEP(0x111, 0xF) MM_RED_STEP(0x112, 0xF) MM_RED_STEP(0x114, 0xF) MM_RED_STEP(0x118, 0xF)
+        MM_RED_STEP(0x142, 0xA) MM_RED_STEP(0x143, 0xC)                                              // lane 63 now holds the wave's reduction
+#undef MM_RED_STEP
+        xU |= ((u64) (u32) __builtin_amdgcn_readlane((int) x1, 63) << 32) | (u32) __builtin_amdgcn_readlane((int) x0, 63);
+        xmin = min(xmin, (u32) __builtin_amdgcn_readlane((int) xn, 63)); xmax = max(xmax, (u32) __builtin_amdgcn_readlane((int) xx, 63));
+        xcnt += fl;
+        if (fl < 64) break;
         nb += 64;
       }
-      if (head && j + tcnt == ((j | 63) + 1)) { tU |= xU; tcnt += xcnt; tmin = min(tmin, xmin); tmax = max(tmax, xmax); }
+      if ((int) lane == hl) { tU |= xU; tcnt += xcnt; tmin = min(tmin, xmin); tmax = max(tmax, xmax); }
     }
+#undef MM_DPP
+    __syncthreads();   // LDS is rewritten by the next round
     if (!head) continue;
     const u32 q = key + qmin;
     if (rem > 0 && tcnt <= rem) {
@@ -1661,7 +1736,8 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
-  HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 1) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
+  HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 2) * 4));   // + the scan's "workgroups done" counter
+  HIPCHK(hipMemset(c->d_rowTot, 0, (RS_ROW_COUNT + 2) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
   HIPCHK(hipMalloc((void **) &c->d_seg, 2 * GT_CAP * 4));
   *out = c;
   return mm_reset(c);
@@ -1771,15 +1847,15 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
   hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
   // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
-  hipLaunchKernelGGL(k_rs_scan_rows, dim3(rebase ? RS_ROW_COUNT + 1 : 256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, 0, fixed_bits);
-  hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, 0, fixed_bits, c->d_hist, nblk, rebase, c->d_walk);
+  hipLaunchKernelGGL(k_rs_scan, dim3(rebase ? RS_ROW_COUNT + 1 : 256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
+                     c->d_M, 0, fixed_bits, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
                      fixed_bits, c->d_hist, c->d_rowTot, nblk);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int shift = 8; shift < max_bits; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
-    hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_M, shift, fixed_bits);
-    hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, c->stream, c->d_rowTot, c->d_M, shift, fixed_bits, c->d_hist, nblk, 0, c->d_walk);
+    hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
+                       fixed_bits, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk);
     std::swap(kin, kout); std::swap(vin, vout);
@@ -1875,7 +1951,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     PhaseTimer t(c, MM_PHASE_MERGE);
     if (dflt)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
-                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
+                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
     else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
       mm_ctx::Run r;
       r.n = n;
