@@ -26,7 +26,9 @@ def short(name):
 
 def counters(d):
     out = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    files = sorted(files, key=os.path.getmtime)[-1:]   # gpurun merges into what is already there: only the newest run counts
+    for f in files:
         for r in csv.DictReader(open(f)):
             out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
@@ -37,6 +39,7 @@ def main():
     os.makedirs("profiles", exist_ok=True)
     ks = glob.glob(os.path.join(base, f"{wl}_trace", "*", "*kernel_stats.csv"))
     if ks:
+        ks = sorted(ks, key=os.path.getmtime)[-1:]
         shutil.copy(ks[0], f"profiles/{rnd}_{wl}_kernel_stats.csv")
     res = {}
     for tag in ("fetch", "write", "l2"):
