@@ -821,6 +821,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     } else if (ok) atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
   }
   __syncthreads();
+  if (presorted) {   // plain ordered compaction: the pairs go straight from the registers to their place, in file order
+    u32 off = hist[(size_t) RS_ROW_COUNT * nblk + blockIdx.x];
+    for (u32 q = 0; q < w; ++q) off += cntw[q][0];
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      const bool valid = (vmask >> r) & 1u;
+      const u64 bal = __ballot(valid);
+      if (valid) { const u32 pos = off + (u32) __popcll(bal & lt); kout[pos] = kreg[r]; vout[pos] = vreg[r]; }
+      off += (u32) __popcll(bal);
+    }
+    return;
+  }
   {  // B: thread t owns digit t
     const u32 c0 = cntw[0][t], c1 = cntw[1][t], c2 = cntw[2][t], c3 = cntw[3][t];
     const u32 tot = c0 + c1 + c2 + c3;
