@@ -605,6 +605,24 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
 // grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
 // payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
 // in file order within each digit, and k_rs_scan publishes their number (INFO_M) for the following passes.
+// Histogram update of one wave.  Read-name ids spread evenly over the digits and plain LDS atomics are best (the
+// aggregation below costs 6 % of the sort there).  -y ratio sorts by table slot, where a handful of rows take most
+// records: then (skewed) the digit of the first pending lane is counted once for all the lanes that share it, twice,
+// before the rest use atomics - this removes the same-address serialisation SQ_WAIT_INST_LDS showed in these kernels.
+__device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewed) {
+  if (!skewed) { if (ok) atomicAdd(&h[d], 1u); return; }
+  const u32 lane = threadIdx.x & 63;
+  u64 pend = __ballot(ok);
+  for (int it = 0; it < 2 && pend; ++it) {
+    const int l0 = __ffsll((long long) pend) - 1;
+    const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
+    const u64 same = __ballot(ok && d == d0) & pend;
+    if ((int) lane == l0) atomicAdd(&h[d0], (u32) __popcll(same));
+    pend &= ~same;
+  }
+  if ((pend >> lane) & 1ull) atomicAdd(&h[d], 1u);
+}
+
 template <bool FIRST>
 __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *__restrict__ vin, const u32 *__restrict__ info, size_t i, size_t n,
                                         int rebase, u32 &k, u32 &v) {
@@ -653,7 +671,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
     const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
     u32 k = 0, v;
     const bool ok = rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v);
-    if (ok) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    wave_hist_add(h, (k >> shift) & 255u, ok, fixed_bits != 0);
     if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
       const u64 below = vm & ((1ull << lane) - 1ull);
@@ -818,7 +836,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     if (presorted) {   // (wave-uniform) all pairs count for digit 0: one add per wave instead of 64 colliding atomics
       const u32 c = (u32) __popcll(__ballot(ok));
       if (lane == 0) cntw[w][0] += c;
-    } else if (ok) atomicAdd(&cntw[w][(kreg[r] >> shift) & 255u], 1u);
+    } else wave_hist_add(cntw[w], (kreg[r] >> shift) & 255u, ok, fixed_bits != 0);
   }
   __syncthreads();
   if (presorted) {   // plain ordered compaction: the pairs go straight from the registers to their place, in file order
