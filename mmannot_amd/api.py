@@ -126,7 +126,7 @@ class IntervalIndex:
     def info(self) -> Dict[str, int]:
         a = (C.c_uint64 * 8)()
         check(lib().mm_index_info(self._h, a))
-        return dict(interval_bytes=a[0], bin_bytes=a[1], active_bytes=a[2], bin_shift=a[3], slot_bytes=a[4], flat_bytes=a[5], slot_shift=a[6])
+        return dict(interval_bytes=a[0], bin_bytes=a[1], active_bytes=a[2], bin_shift=a[3], slot_bytes=a[4], flat_bytes=a[5], slot_shift=a[6], slot_bitmap_bytes=a[7])
 
     def close(self):
         if getattr(self, "_h", None):
