@@ -107,7 +107,7 @@ int mm_index_create(mm_index **out, const mm_elements *elems, int32_t n_chromoso
                     const uint8_t *strand, int device, int bin_shift);
 void mm_index_destroy(mm_index *ix);
 /* sizes of the device structures (bytes): full index [0]=interval records [1]=bin table [2]=active lists [3]=its bin shift;
- * compact index [4]=slots (128 B per bin) [5]=flat record lists [6]=its bin shift [7]=bitmap of non-empty slots (0 = not used) */
+ * compact index [4]=slots (64 B per bin) [5]=flat record lists [6]=its bin shift [7]=bitmap of non-empty slots (0 = not used) */
 int mm_index_info(const mm_index *ix, uint64_t info[8]);
 
 /* ---- context: replaces Counter (clear/read/getCounts/dump). stream: hipStream_t or NULL (a private stream). */

@@ -14,7 +14,7 @@
 //   act(b)  = the intervals open at the bin's left edge (start < b*W <= end+1), in index order, followed by
 //   iv(b..) = the intervals starting at or after b*W, in index order, while start <= read.end,
 // visited in the reference's index order (which matters: EvaluationStructure::set is last-writer-wins).  Two encodings:
-//   * compact slots (probe_slots): one 128-B line per bin with up to 15 packed 8-B records - every read with end >= start;
+//   * compact slots (probe_slots): one 64-B sector per bin with up to 7 packed 8-B records - every read with end >= start;
 //   * full 16-B records + bins + active lists (probe_one): reads without CIGAR operations (they need the "leading
 //     isBefore run" rule, which uses each record's prefix-max of ends) and the -M interval listing.
 // Downstream of the probe: multi-hit records are stably radix-sorted by read-name id and reduced per name (k_rs_*,
@@ -107,8 +107,8 @@ struct ProbeParams {
   const uint2 *bins;       // per chromosome nbins+1 entries {first, actOff}
   const uint4 *chrInfo;     // per chromosome {first bin record, number of bins, end of its interval range, 0}
   // compact "slot" index used for every read with end >= start (see slot_walk)
-  const uint4 *slots;       // 128 B per bin: {nAct | nIv<<16, offset into flat, rec0} {rec1, rec2} ... 15 records
-  const uint2 *flat;        // every bin's full record list (only read when a bin holds more than 15 records)
+  const uint4 *slots;       // 64 B per bin: {nAct | nIv<<16, offset into flat, rec0} {rec1, rec2} ... 7 records
+  const uint2 *flat;        // every bin's full record list (only read when a bin holds more than 7 records)
   const uint2 *chrSlot;     // per chromosome {first slot, number of slots}
   const u32 *slotBits;      // one bit per slot: does it hold any record?  NULL when too few slots are empty for the test to pay
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
@@ -316,7 +316,7 @@ __device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c
 // 8-byte candidate record: x = start; y = len:22 | type:6 | ok('-' read):1 | ok('+' read):1 | long:1 | 0.
 // The two "ok" bits are checkStrand (mmannot.cpp:438-443) evaluated at build time for both read strands.
 // A bin's slot lists, in index order, the intervals open at the bin's left edge followed by the intervals
-// starting inside the bin: exactly act(b) ++ iv[first(b)..] of the 16-byte structure, one cache line.
+// starting inside the bin: exactly act(b) ++ iv[first(b)..] of the 16-byte structure, one 64-B sector.
 #define REC_LEN_BITS 22
 #define REC_LEN_MASK ((1u << REC_LEN_BITS) - 1u)
 #define REC_TYPE(y) (((y) >> REC_LEN_BITS) & 63u)
@@ -345,8 +345,8 @@ __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, i
 // The slot walk, written once as a statement macro and expanded with two visitors (plain straight-line code: callbacks made
 // the compiler keep closures and a copy of the parameter block in scratch).  VISIT(rx, ry) sees, in index order, every
 // record that can concern the read [s,e] (e >= s): the whole slot of the bin of s, then only the "starts here" part of
-// the following bins up to the bin of e.  The slot's first 32 bytes (header + 3 records) are requested first, the rest
-// of its first half and its second half only when the header says they hold records - and nothing at all when the
+// the following bins up to the bin of e.  The slot's first 32 bytes (header + 3 records) are requested first, its
+// second 32 bytes only when the header says they hold records - and nothing at all when the
 // slot is empty, which a bitmap small enough to stay in L2 (1 bit per bin) tells: the kernel's limit is the number of
 // random 64-B sector fetches it can keep in flight, and about half of the bins of a genome hold no record.  The test is
 // a dependent L2 access of its own, so the index only carries the bitmap when at least 42 % of the slots are empty
@@ -354,7 +354,7 @@ __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, i
 #define MM_SLOT_WALK(VISIT)                                                                      \
   for (u32 b_ = b0; b_ <= b1; ++b_) {                                                            \
     if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue; /* empty bin: no line to fetch */ \
-    const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 8;                                        \
+    const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;                                        \
     const uint4 q0 = S_[0], q1 = S_[1];                                                          \
     const u32 nAct_ = q0.x & 0xffffu, n_ = nAct_ + (q0.x >> 16);                                 \
     const u32 first_ = (b_ == b0) ? 0u : nAct_;                                                  \
@@ -368,16 +368,7 @@ __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, i
       if (first_ <= 5 && n_ > 5) VISIT(q3.x, q3.y)                                               \
       if (first_ <= 6 && n_ > 6) VISIT(q3.z, q3.w)                                               \
       if (n_ > 7) {                                                                              \
-        const uint4 q4 = S_[4], q5 = S_[5], q6 = S_[6], q7 = S_[7];                              \
-        if (first_ <= 7) VISIT(q4.x, q4.y)                                                       \
-        if (first_ <= 8 && n_ > 8) VISIT(q4.z, q4.w)                                             \
-        if (first_ <= 9 && n_ > 9) VISIT(q5.x, q5.y)                                             \
-        if (first_ <= 10 && n_ > 10) VISIT(q5.z, q5.w)                                           \
-        if (first_ <= 11 && n_ > 11) VISIT(q6.x, q6.y)                                           \
-        if (first_ <= 12 && n_ > 12) VISIT(q6.z, q6.w)                                           \
-        if (first_ <= 13 && n_ > 13) VISIT(q7.x, q7.y)                                           \
-        if (first_ <= 14 && n_ > 14) VISIT(q7.z, q7.w)                                           \
-        for (u32 k_ = max(15u, first_); k_ < n_; k_ += 4) { /* rare long lists: four loads in flight */ \
+        for (u32 k_ = max(7u, first_); k_ < n_; k_ += 4) { /* rare long lists: four loads in flight */ \
           const uint2 *F_ = P.flat + q0.y;                                                       \
           const uint2 r0 = F_[k_], r1 = F_[min(k_ + 1, n_ - 1)], r2 = F_[min(k_ + 2, n_ - 1)], r3 = F_[min(k_ + 3, n_ - 1)]; \
           VISIT(r0.x, r0.y)                                                                      \
@@ -1634,16 +1625,17 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   std::vector<uint2> flat;
   std::vector<int> longEnd;
   {
-    // Bin width.  A wave is as slow as its slowest lane, and bins holding more than 15 records leave the one-line
-    // fast path, so the widest bin width is chosen whose share of such bins stays below 0.2 % (64 lanes: most waves
-    // then never see one), among the widths whose table (128 B per bin) fits 256 MB.  Record counts per bin are
-    // heavy-tailed (gene-dense regions), which is why the mean is not the criterion.
+    // Bin width.  Bins holding more than 7 records leave the one-sector fast path (their list continues in `flat`),
+    // so the widest bin width is chosen whose share of such bins stays below 2 %, among the widths whose table (64 B
+    // per bin) fits 256 MB.  Record counts per bin are heavy-tailed (gene-dense regions), which is why the mean is
+    // not the criterion.  (Measured against 128-B slots holding 15 records at twice the width - the same table size:
+    // probe time -3.5 % HS38-shaped, -4 % TAIR10-shaped, -12 % Flybase6-shaped.)
     int best = -1, fallback = -1;
     for (int sh = 20; sh >= 7; --sh) {
       u64 nb = 0;
       std::vector<u64> base(n_chromosomes + 1, 0);
       for (int c = 0; c < n_chromosomes; ++c) { base[c] = nb; if (seen[c]) nb += (u64) (maxEnd[c] >> sh) + 2; }
-      if (nb * 128ull > (256ull << 20)) break;
+      if (nb * 64ull > (256ull << 20)) break;
       fallback = sh;
       std::vector<int32_t> diff(nb + 2, 0), cnt(nb + 1, 0);
       for (size_t i = 0; i < n_iv; ++i) {
@@ -1654,8 +1646,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       }
       u64 over = 0;
       int32_t run = 0;
-      for (u64 k = 0; k <= nb; ++k) { run += diff[k]; if (cnt[k] + run > 15) ++over; }
-      if ((double) over <= 0.002 * (double) nb) { best = sh; break; }
+      for (u64 k = 0; k <= nb; ++k) { run += diff[k]; if (cnt[k] + run > 7) ++over; }
+      if ((double) over <= 0.02 * (double) nb) { best = sh; break; }
     }
     if (best < 0) best = fallback < 0 ? 20 : fallback;
     const int sh = bin_shift > 0 ? std::min(std::max(bin_shift, 7), 20) : best;
@@ -1697,15 +1689,15 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       for (u32 b = b0; b <= b1; ++b) flat[curA[sBase[c] + b]++] = rec;
     }
     if (longEnd.size() >= REC_LEN_MASK) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: too many very long intervals"); }
-    slots.assign(ns * 8, make_uint4(0u, 0u, 0u, 0u));
+    slots.assign(ns * 4, make_uint4(0u, 0u, 0u, 0u));
     slotBits.assign((ns + 31) / 32 + 1, 0u);
     for (u64 k = 0; k < ns; ++k) {
       if (nAct[k] + nIv[k]) slotBits[k >> 5] |= 1u << (k & 31);
-      u32 *w = (u32 *) &slots[k * 8];
+      u32 *w = (u32 *) &slots[k * 4];
       w[0] = nAct[k] | (nIv[k] << 16);
       w[1] = (u32) off[k];
       if (nAct[k] > 0xFFFFu || nIv[k] > 0xFFFFu) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: more than 65535 intervals in one bin; lower bin_shift"); }
-      const u32 n = std::min<u32>(nAct[k] + nIv[k], 15u);
+      const u32 n = std::min<u32>(nAct[k] + nIv[k], 7u);
       for (u32 r = 0; r < n; ++r) { w[2 + 2 * r] = flat[off[k] + r].x; w[3 + 2 * r] = flat[off[k] + r].y; }
     }
     u64 nonEmpty = 0;
@@ -1750,7 +1742,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
 extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
   if (!ix || !info) return fail(MM_ERR_ARG, "mm_index_info: null argument");
   info[0] = ix->n_iv * sizeof(int4); info[1] = ix->n_bins * sizeof(uint2); info[2] = ix->n_act * sizeof(int4); info[3] = (u64) ix->shift;
-  info[4] = ix->n_slots * 128ull; info[5] = ix->n_flat * sizeof(uint2); info[6] = (u64) ix->sshift; info[7] = ix->n_slotBits * sizeof(u32);
+  info[4] = ix->n_slots * 64ull; info[5] = ix->n_flat * sizeof(uint2); info[6] = (u64) ix->sshift; info[7] = ix->n_slotBits * sizeof(u32);
   return MM_OK;
 }
 
