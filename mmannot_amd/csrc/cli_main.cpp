@@ -4,6 +4,7 @@
 // acts together with -m) is the reference's "slow" side channel: the per-hit element sets come
 // back from the device and the multiset bookkeeping of printReadStats/rescue (mmannot.cpp:474-509) is done here.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -212,14 +213,24 @@ int main(int argc, char **argv) {
   if (read_stats) read_stats_out.open(read_stats_file.c_str());
   if (interval_stats) interval_stats_out.open(interval_stats_file.c_str());
 
+  // MM_CLI_TIMING=1: one extra stderr line with the wall time of the phases (not part of the reference's output)
+  const bool timing = getenv("MM_CLI_TIMING") && *getenv("MM_CLI_TIMING") && *getenv("MM_CLI_TIMING") != '0';
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  double t_annot = 0, t_index = 0, t_decode = 0, t_device = 0, t_host = 0;
+  uint64_t n_records = 0;
+  const auto t_start = now();
   mm_annotation *an = nullptr;
   if (mm_annotation_load(&an, config.c_str(), gtf.c_str(), upstream, downstream) != MM_OK) {
     std::cerr << mm_annotation_error() << std::endl;
     return EXIT_FAILURE;
   }
   std::cerr << mm_annotation_log(an);
+  t_annot = secs(t_start, now());
   mm_index *index = nullptr;
+  { const auto t0 = now();
   if (mm_index_from_annotation(&index, an, device, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+  t_index = secs(t0, now()); }
   mm_options opt;
   opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
   opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0; opt.defer_ratio = 0;
@@ -282,13 +293,18 @@ int main(int argc, char **argv) {
     uint64_t cpt = 0;
     for (;;) {
       size_t n = 0;
+      const auto t0 = now();
       rc = mm_reader_next(rd, aln.data(), nh.data(), BATCH, &n);
       std::cerr << mm_reader_take_log(rd);
       if (rc != MM_OK) { std::cerr << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+      const auto t1 = now();
+      t_decode += secs(t0, t1);
       if (n == 0) break;
+      n_records += n;
       if (mm_annotate_batch(ctx, aln.data(), nh.data(), n, mm_reader_qid_bound(rd), 0) != MM_OK || mm_sync(ctx) != MM_OK) {
         std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
       }
+      t_device += secs(t1, now());
       if (host_book) {
         hm.resize(n);
         if (mm_get_hit_masks(ctx, hm.data(), n) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
@@ -432,5 +448,11 @@ int main(int argc, char **argv) {
   if (interval_stats) interval_stats_out.close();
   mm_ctx_destroy(ctx); mm_index_destroy(index); mm_annotation_free(an);
   std::cerr << "Successfully done." << std::endl;
+  if (timing) {
+    const double total = secs(t_start, now());
+    t_host = total - t_annot - t_index - t_decode - t_device;
+    fprintf(stderr, "[mmannot-amd timing] total %.3f s: annotation %.3f, index %.3f, waiting for the decoder %.3f, device %.3f, other host %.3f; %llu records, %.2f M records/s\n",
+            total, t_annot, t_index, t_decode, t_device, t_host, (unsigned long long) n_records, n_records / total / 1e6);
+  }
   return 0;
 }

@@ -332,24 +332,33 @@ def write_bam(path: str, chroms: Sequence[Tuple[str, int]], records: Sequence[by
 
 
 def bam_records_fixed(tid: np.ndarray, pos0: np.ndarray, flag: np.ndarray, qname_id: np.ndarray, read_len: np.ndarray,
-                      nh: Optional[np.ndarray], name_width: int = 10) -> bytes:
+                      nh: Optional[np.ndarray], name_width: int = 10, seq_len: int = 0) -> bytes:
     """Vectorised writer for large synthetic BAMs: every record is `<len>M`, name = zero-padded
     decimal of qname_id (fixed width), one NH:I tag (or none).  Returns the record bytes."""
     n = len(tid)
     lname = name_width + 1
     has_nh = nh is not None
-    # we store seq_len = 0 (the reference skips (l_seq+1)/2 + l_seq bytes, mmannot.cpp:1558-1559) to keep files small
-    rec_len = 32 + lname + 4 + (7 if has_nh else 0)
+    # seq_len = 0 by default (the reference skips (l_seq+1)/2 + l_seq bytes, mmannot.cpp:1558-1559) to keep files small;
+    # seq_len > 0 adds random bases and qualities, the bulk of a real BAM record
+    nseq = (seq_len + 1) // 2 + seq_len
+    rec_len = 32 + lname + 4 + nseq + (7 if has_nh else 0)
     dt = [("block_size", "<i4"), ("tid", "<i4"), ("pos", "<i4"), ("l_read_name", "u1"), ("mapq", "u1"),
           ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_tid", "<i4"),
           ("next_pos", "<i4"), ("tlen", "<i4"), ("name", f"S{lname}"), ("cigar", "<u4")]
+    if nseq:
+        dt += [("seq", "u1", ((seq_len + 1) // 2,)), ("qual", "u1", (seq_len,))]
     if has_nh:
         dt += [("nh_key", "S3"), ("nh_val", "<u4")]
     a = np.zeros(n, dtype=np.dtype(dt))
     assert a.dtype.itemsize == rec_len + 4
     a["block_size"] = rec_len
     a["tid"] = tid; a["pos"] = pos0; a["l_read_name"] = lname; a["mapq"] = 255; a["bin"] = 4680
-    a["n_cigar"] = 1; a["flag"] = flag; a["l_seq"] = 0; a["next_tid"] = -1; a["next_pos"] = -1
+    a["n_cigar"] = 1; a["flag"] = flag; a["l_seq"] = seq_len; a["next_tid"] = -1; a["next_pos"] = -1
+    if nseq:
+        rng = np.random.default_rng(12345)
+        a["seq"] = rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88], dtype=np.uint8),
+                              size=(n, (seq_len + 1) // 2))
+        a["qual"] = rng.integers(20, 41, size=(n, seq_len), dtype=np.uint8)
     digits = np.zeros((n, lname), dtype=np.uint8)
     q = qname_id.astype(np.int64).copy()
     for k in range(name_width - 1, -1, -1):

@@ -32,7 +32,8 @@ def main():
     cfg = os.path.join(d, "c.cfg"); open(cfg, "w").write(synth.config_text(a.shape))
     n = 1 << a.reads_log2
     t = sr.synth_tuples(7, 0, n, 100, 6, an.chr_len, 8)
-    body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"], np.full(n, 100), t["nh"])
+    body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"], np.full(n, 100), t["nh"],
+                                **({"seq_len": 100} if a.seq else {}))
     bam = os.path.join(d, "r.bam")
     mo.write_bam_bgzf(bam, [(c, int(l)) for c, l in zip(an.chr_names, an.chr_len)], body, level=1)
     res = {}
@@ -42,8 +43,12 @@ def main():
             continue
         out = os.path.join(d, name.split()[0] + ".tsv")
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "-a", gtf, "-c", cfg, "-r", bam, "-s", "F", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        p = subprocess.run([exe, "-a", gtf, "-c", cfg, "-r", bam, "-s", "F", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, MM_CLI_TIMING="1"))
         dt = time.perf_counter() - t0
+        for line in p.stderr.decode().splitlines():
+            if line.startswith("[mmannot-amd timing]"):
+                print("   ", line)
         res[name] = (dt, open(out).read() if p.returncode == 0 else p.stderr.decode()[-300:])
         print(f"{name}: {dt:.2f} s wall, {n / dt / 1e6:.2f} M records/s end to end (rc {p.returncode})")
     tabs = [v[1] for v in res.values()]
