@@ -68,7 +68,7 @@ def main():
     import torch.distributed as dist
     import mmannot_amd as mm
     from mmannot_amd import _lib, synth
-    from mmannot_amd.dist import chain_ratio, merge_counts
+    from mmannot_amd.dist import chain_ratio, merge_counts, warm_up
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,6 +135,11 @@ def main():
     ctr.sync()
     ctr.set_profiling(True)
     if world > 1:
+        # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
+        if strategy == "ratio":
+            warm_up(device=comm_dev, p2p=True)
+        else:
+            merge_counts(*ctr.getCounts(), ctr.stats(), device=comm_dev)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

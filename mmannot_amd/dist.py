@@ -17,6 +17,25 @@ import torch
 import torch.distributed as dist
 
 
+def warm_up(device=None, group=None, p2p: bool = False) -> None:
+    """One tiny call of every collective the merge uses (and, for the -y ratio chain, a send/recv round along the ranks):
+    RCCL sets its channels and kernels up on first use, which would otherwise land inside a timed region."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    x = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.all_gather([torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)], x, group=group)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+    dist.broadcast(x, src=ws - 1, group=group)
+    if p2p:
+        if rank > 0:
+            dist.recv(x, src=rank - 1, group=group)
+        if rank < ws - 1:
+            dist.send(x, dst=rank + 1, group=group)
+    dist.barrier(group=group)
+
+
 def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], device=None, group=None) -> Tuple[np.ndarray, np.ndarray, Dict[str, int]]:
     """masks uint64[n], sums float64[n] (integral), stats dict -> merged (masks, sums, stats), identical on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -42,3 +42,18 @@ def test_two_ranks_share_one_gpu_gloo(gpu_lib):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_ratio_chain_gloo(gpu_lib):
+    """-y ratio on two ranks: deferred accumulation + rank-to-rank chain (dist.chain_ratio), collectives warmed up before timing."""
+    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20",
+                        "--workload", "c5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = _json_lines(p.stdout.decode())
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and d["table_rows"] > 0
