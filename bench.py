@@ -51,7 +51,7 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30, help="timed batches (default 30 x 2^24 = 503 M alignments: BASELINE.json's configs[2] on one GPU)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-log2", type=int, default=24)
