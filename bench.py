@@ -133,7 +133,7 @@ def main():
     for s in range(args.warmup):
         run_step(s)
     ctr.sync()
-    ctr.set_profiling(True)
+    ctr.set_profiling(os.environ.get("MM_BENCH_NO_EVENTS", "") == "")   # (switch for measuring the cost of the event records themselves)
     if world > 1:
         # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
         if strategy == "ratio":
@@ -172,7 +172,7 @@ def main():
         dom = max(("probe", "sort", "merge", "compact"), key=lambda p: phases[p][0])
         probe_ms, probe_n = phases["probe"]
         avg_probe_s = probe_ms / max(1, probe_n) / 1e3
-        achieved = B_ALG_PROBE * B / avg_probe_s / 1e9
+        achieved = B_ALG_PROBE * B / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
         traffic = None
         pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pj):
