@@ -67,7 +67,7 @@ struct BgzfPipe {
   bool open(const char *path) {
     f = fopen(path, "rb");
     if (!f) return false;
-    n_threads = (int) std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    n_threads = (int) std::max(1u, std::min(16u, std::thread::hardware_concurrency()));   // a GPU's share of the host cores
     producer = std::thread([this] { run(); });
     return true;
   }
@@ -231,9 +231,10 @@ namespace {
 struct NameDict {
   std::vector<char> arena;            // names back to back, each NUL-terminated
   std::vector<uint64_t> name_off;     // id -> offset in arena
-  std::vector<uint32_t> table;        // slot -> id + 1 (0 = empty)
-  std::vector<uint32_t> hashes;       // id -> 32-bit hash (cheap pre-compare, reused when growing)
+  std::vector<uint64_t> table;        // slot -> (32-bit hash << 32) | (id + 1), 0 = empty: a miss costs one cache line, not three
+  std::vector<uint32_t> hashes;       // id -> 32-bit hash (reused when growing)
   size_t mask = 0;
+  uint32_t last = 0xFFFFFFFFu;        // id of the previous lookup: an aligner writes the hits of a read one after the other
   static uint64_t hash(const char *p, size_t n) {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
     while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; p += 8; n -= 8; }
@@ -247,22 +248,27 @@ struct NameDict {
     for (uint32_t id = 0; id < name_off.size(); ++id) {
       size_t s = hashes[id] & mask;
       while (table[s]) s = (s + 1) & mask;
-      table[s] = id + 1;
+      table[s] = ((uint64_t) hashes[id] << 32) | (uint64_t) (id + 1);
     }
   }
   uint32_t size() const { return (uint32_t) name_off.size(); }
   const char *name(uint32_t id) const { return id < name_off.size() ? arena.data() + name_off[id] : ""; }
-  uint32_t get(const char *p, size_t n) {
+  bool same(uint32_t id, const char *p, size_t n) const {
+    const char *q = arena.data() + name_off[id];
+    return strncmp(q, p, n) == 0 && q[n] == 0;    // (stops at q's NUL: never reads past the stored name)
+  }
+  void prefetch(uint32_t h) const { if (mask) __builtin_prefetch(&table[h & mask]); }
+  uint32_t get(const char *p, size_t n) { return get(p, n, (uint32_t) hash(p, n)); }
+  uint32_t get(const char *p, size_t n, uint32_t h) {
+    if (last != 0xFFFFFFFFu && same(last, p, n)) return last;
     if ((name_off.size() + 1) * 2 > table.size()) grow();
-    const uint32_t h = (uint32_t) hash(p, n);
     size_t s = h & mask;
     for (;;) {
-      const uint32_t e = table[s];
+      const uint64_t e = table[s];
       if (!e) break;
-      const uint32_t id = e - 1;
-      if (hashes[id] == h) {
-        const char *q = arena.data() + name_off[id];
-        if (strncmp(q, p, n) == 0 && q[n] == 0) return id;
+      if ((uint32_t) (e >> 32) == h) {
+        const uint32_t id = (uint32_t) e - 1;
+        if (same(id, p, n)) return last = id;
       }
       s = (s + 1) & mask;
     }
@@ -271,8 +277,8 @@ struct NameDict {
     arena.insert(arena.end(), p, p + n);
     arena.push_back('\0');
     hashes.push_back(h);
-    table[s] = id + 1;
-    return id;
+    table[s] = ((uint64_t) h << 32) | (uint64_t) (id + 1);
+    return last = id;
   }
 };
 
@@ -305,6 +311,7 @@ struct mm_reader {
   int32_t cur_ref = -2;                              // reference id of the current BAM record (-2: use the name)
   char name_buf[512];
   size_t name_len = 0;
+  bool allow_fast = true;            // MM_READER_GENERAL=1 sends every record through the general parser (differential tests)
   std::vector<std::string> unknown_warned;
   uint64_t n_reads = 0;
   uint64_t cur_end = 0;   // Read::end of the read delivered last (a '*' CIGAR of an alternative keeps it)
@@ -398,6 +405,84 @@ static bool next_sam_record(mm_reader *r) {
     r->err = "cannot parse SAM line (the reference terminates on the uncaught exception): " + line;
     return false;
   }
+  return true;
+}
+
+// Fast path for a BAM record that lies completely inside the current inflated buffer and holds nothing unusual: fields are
+// read in place, the end coordinate comes straight from the packed CIGAR, the name stays where it is.  Anything the general
+// parser treats specially - a CIGAR operation it complains about, tag types H / B / unknown, an XA tag, a record that is
+// malformed or crosses the buffer's end - returns false without consuming a byte, and the general parser (which carries the
+// reference's exact behaviour for those cases, mmannot.cpp:1533-1650) takes the record.
+struct FastRec { uint64_t start, end; const char *name; uint32_t name_len, hash, nhits; int32_t ref; bool strand; };
+static bool fast_bam_record(mm_reader *r, FastRec &out) {
+  ByteSource &s = r->src;
+  if (s.len - s.pos < 36) return false;
+  const uint8_t *b = s.p + s.pos;
+  int32_t size, chr_id, pos, l_seq;
+  uint32_t bin_mq_nl, flag_nc;
+  memcpy(&size, b, 4);
+  if (size < 32 || s.len - s.pos - 4 < (size_t) size) return false;
+  b += 4;
+  memcpy(&chr_id, b, 4); memcpy(&pos, b + 4, 4); memcpy(&bin_mq_nl, b + 8, 4); memcpy(&flag_nc, b + 12, 4); memcpy(&l_seq, b + 16, 4);
+  const int32_t l_name = (int32_t) (bin_mq_nl & 0xff), n_cigar = (int32_t) (flag_nc & 0xffff);
+  if (l_seq < 0 || l_name == 0) return false;
+  const int64_t off = 32 + (int64_t) l_name + 4 * (int64_t) n_cigar + ((int64_t) l_seq + 1) / 2 + (int64_t) l_seq;
+  if (off > size) return false;
+  int32_t ref;
+  if (chr_id == -1) ref = (int32_t) r->bam_chr.size() - 1;
+  else if (chr_id >= 0 && (size_t) chr_id + 1 < r->bam_chr.size()) ref = chr_id;
+  else return false;
+  const char *name = (const char *) (b + 32);
+  const size_t name_len = strnlen(name, (size_t) l_name);
+  if (name_len == (size_t) l_name) return false;            // no terminating NUL inside the name field
+  const uint64_t start = (uint64_t) (int64_t) (pos + 1);
+  uint64_t end = start;
+  const uint8_t *cg = b + 32 + l_name;
+  for (int32_t i = 0; i < n_cigar; ++i) {
+    uint32_t v;
+    memcpy(&v, cg + 4 * i, 4);
+    switch (v & 15u) {
+      case 0: case 2: case 7: case 8: end += (uint64_t) (v >> 4); break;   // M D = X   (Read::parseCigar, mmannot.cpp:852-875)
+      case 1: case 4: case 5: case 6: break;                             // I S H P
+      default: return false;                                             // N and the undefined codes: the general parser complains
+    }
+  }
+  end -= 1;
+  uint32_t nh = 1, nm = r->nmismatches;
+  int64_t i = off;
+  while (i + 1 < size) {                                                  // (the reference's loop bound, mmannot.cpp:1563)
+    if (i + 3 > size) return false;
+    const uint8_t k0 = b[i], k1 = b[i + 1], ty = b[i + 2];
+    i += 3;
+    uint32_t v = 0;
+    switch (ty) {
+      case 'A': case 'c': i += 1; break;
+      case 'C': if (i + 1 > size) return false; v = b[i]; i += 1; break;
+      case 's': i += 2; break;
+      case 'S': { if (i + 2 > size) return false; uint16_t h; memcpy(&h, b + i, 2); v = h; i += 2; break; }
+      case 'i': case 'f': i += 4; break;
+      case 'I': if (i + 4 > size) return false; memcpy(&v, b + i, 4); i += 4; break;
+      case 'Z': {
+        if (k0 == 'X' && k1 == 'A') return false;                         // alternative hits: general parser
+        const void *z = i < size ? memchr(b + i, 0, (size_t) (size - i)) : nullptr;
+        if (!z) return false;
+        i = (const uint8_t *) z - b + 1;
+        break;
+      }
+      default: return false;
+    }
+    if (i > size) return false;
+    if (k0 == 'N' && k1 == 'H') nh = v;
+    else if (k0 == 'N' && k1 == 'M') nm = v;
+  }
+  if (i != size) return false;                                           // a stray trailing byte: the general parser reproduces what follows
+  // commit
+  s.pos += 4 + (size_t) size;
+  r->nmismatches = nm;                                                   // (survives from record to record, like the reference's)
+  out.start = start; out.end = end; out.name = name; out.name_len = (uint32_t) name_len; out.nhits = nh; out.ref = ref;
+  out.strand = ((flag_nc >> 16) & 0x10) == 0;
+  out.hash = (uint32_t) NameDict::hash(name, name_len);
+  r->qids.prefetch(out.hash);
   return true;
 }
 
@@ -506,6 +591,7 @@ extern "C" int mm_reader_open(mm_reader **out, const char *path, int format, con
   *out = nullptr;
   mm_reader *r = new mm_reader();
   r->path = path; r->an = an; r->strand_compat = strand_compat; r->unique_only = unique_only != 0; r->keep_names = keep_names != 0;
+  { const char *e = getenv("MM_READER_GENERAL"); r->allow_fast = !(e && *e && *e != '0'); }
   *out = r;
   bool bam;
   if (format == MM_FMT_BAM) bam = true;
@@ -555,6 +641,38 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
   size_t n = 0;
   uint64_t &cur_end = r->cur_end;
   while (n < cap && !r->over) {
+    // Runs of ordinary BAM records: parsed in place a few at a time, so that the read-name dictionary's cache misses
+    // (requested while parsing) overlap instead of adding up; then finished one by one in file order.
+    if (r->is_bam && r->allow_fast && !(r->have_record && r->alt_next < r->alts.size())) {
+      FastRec fr[32];
+      size_t m = 0;
+      while (m < 32 && n + m < cap && fast_bam_record(r, fr[m])) ++m;
+      if (m) {
+        for (size_t k = 0; k < m; ++k) {
+          const FastRec &f = fr[k];
+          if (f.start > 0x7FFFFFF0ull || (f.end > 0x7FFFFFF0ull && f.end != f.start - 1)) {
+            r->err = std::string("alignment coordinate outside the supported range [0, 2^31) for read ") + std::string(f.name, f.name_len);
+            *n_out = n; return MM_ERR_RANGE;
+          }
+          const bool strand = (r->strand_compat == MM_STRAND_COMPAT_PLUS) ? true : (r->strand_compat == MM_STRAND_COMPAT_MINUS ? false : f.strand);
+          const bool reaches_scan = !r->unique_only || f.nhits == 1;   // mmannot.cpp:1773
+          int32_t tid = r->bam_tid[f.ref];
+          if (tid == -2 || (tid < 0 && reaches_scan)) { tid = tid_of(r, r->bam_chr[f.ref], reaches_scan); r->bam_tid[f.ref] = tid; }
+          aln[n].start = (int32_t) f.start;
+          aln[n].end = (int32_t) (int64_t) f.end;
+          aln[n].tid_strand = MM_ALN_TID_STRAND(tid, strand);
+          aln[n].qid = r->qids.get(f.name, f.name_len, f.hash);
+          nh[n] = f.nhits;
+          ++n; ++r->n_reads;
+        }
+        // state the general path and the end-of-file replay look at: the last record, which has nothing to complain about
+        const FastRec &l = fr[m - 1];
+        r->cigar.clear(); r->alts.clear(); r->alt_next = 0; r->have_record = true;
+        r->cur_ref = l.ref; r->rec_start = l.start; r->rec_strand = l.strand; r->nhits = l.nhits; r->cur_end = l.end;
+        r->name_len = std::min((size_t) l.name_len, sizeof(r->name_buf) - 1); memcpy(r->name_buf, l.name, r->name_len); r->name_buf[r->name_len] = 0;
+        continue;
+      }
+    }
     std::string chr;
     bool strand, is_alt = false;
     uint64_t start, end;

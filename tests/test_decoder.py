@@ -57,3 +57,58 @@ def test_truncated_bgzf_is_an_error(oracle, tmp_path):
     open(b, "wb").write(raw[:len(raw) // 2 + 3])
     with pytest.raises(MMError):
         api.ReadsDecoder(str(b), an).read_all()
+
+
+def _decode(path, an, cap=None):
+    import mmannot_amd.api as api
+    d = api.ReadsDecoder(path, an)
+    a, h = d.read_all() if cap is None else d.read_all(cap=cap)
+    return a, h, d.take_log().replace(path, "F"), d.qid_bound(), [d.name(q) for q in range(min(d.qid_bound(), 50))]
+
+
+def test_fast_record_path_equals_general_parser(oracle, tmp_path, monkeypatch):
+    """mm_reads.cpp:fast_bam_record (fields read in place) against the general parser (MM_READER_GENERAL=1), which the KATs and
+    the synthetic end-to-end goldens pin against the compiled reference: every known-answer BAM (odd CIGAR operations, NH in
+    every tag type, XA, B/H arrays) and a large synthetic one with tags of all plain types, as BGZF and as one gzip member."""
+    import mmannot_amd.api as api
+    files = []
+    for k in sorted(os.listdir(os.path.join(gu.GOLD, "kat"))):
+        b = os.path.join(gu.GOLD, "kat", k, "r.bam")
+        if os.path.exists(b):
+            files.append((k, b, api.Annotation(os.path.join(gu.GOLD, "kat", k, "c.cfg"), os.path.join(gu.GOLD, "kat", k, "a.gtf"))))
+    assert len(files) >= 8
+    # synthetic: names of varying length, 0..3 CIGAR operations incl. I/S/D, tags A c C s S i I f Z in random order around NH / NM
+    import struct
+    rng = np.random.default_rng(11)
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+    recs = []
+    for i in range(20000):
+        ops = [("MIDS=X"[int(rng.integers(0, 6))], int(rng.integers(1, 90))) for _ in range(int(rng.integers(0, 4)))]
+        tags = b""
+        for _ in range(int(rng.integers(0, 5))):
+            t = "AcCsSiIfZ"[int(rng.integers(0, 9))]
+            key = ["NH", "NM", "XS", "ZZ", "AS"][int(rng.integers(0, 5))]
+            tags += key.encode() + t.encode()
+            if t == "A":
+                tags += b"x"
+            elif t == "Z":
+                tags += b"some text\0"
+            elif t == "f":
+                tags += struct.pack("<f", 1.5)
+            else:
+                tags += struct.pack(fmt[t], int(rng.integers(0, 100)))
+        recs.append(oracle._bam_record(int(rng.integers(-1, 2)), int(rng.integers(0, 90000)), int(rng.integers(0, 2)) * 16,
+                                       "r%d" % int(rng.integers(0, 4000)), ops, int(rng.integers(0, 3)) * 25, tags))
+    chroms = [("chr1", 100000), ("chrZ", 50000)]
+    p0, p1 = str(tmp_path / "s.bam"), str(tmp_path / "sb.bam")
+    oracle.write_bam(p0, chroms, recs)
+    oracle.write_bgzf(p1, _bam_payload(p0), level=1, block=3001)
+    an0 = files[0][2]
+    files += [("synthetic gzip", p0, an0), ("synthetic bgzf", p1, an0)]
+    for label, path, an in files:
+        monkeypatch.delenv("MM_READER_GENERAL", raising=False)
+        fast = _decode(path, an)
+        monkeypatch.setenv("MM_READER_GENERAL", "1")
+        gen = _decode(path, an)
+        assert (fast[0] == gen[0]).all() and (fast[1] == gen[1]).all(), label
+        assert fast[2:] == gen[2:], label
