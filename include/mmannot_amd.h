@@ -102,6 +102,8 @@ const char *mm_version(void);
  * Input = the interval vector *after* the reference's std::sort (order is significant:
  * EvaluationStructure::set is last-writer-wins, mmannot.cpp:1023-1028), chr ascending.
  * bin_shift: log2 of the device bin width, 0 = choose automatically. */
+/* number of HIP devices visible to the process (0 when there is none) */
+int mm_device_count(void);
 int mm_index_create(mm_index **out, const mm_elements *elems, int32_t n_chromosomes, size_t n_intervals,
                     const int32_t *chr, const int32_t *start, const int32_t *end, const uint8_t *type,
                     const uint8_t *strand, int device, int bin_shift);

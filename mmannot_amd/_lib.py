@@ -50,6 +50,7 @@ _lib = None
 SYMBOLS = {
     "mm_last_error": (C.c_char_p, []),
     "mm_version": (C.c_char_p, []),
+    "mm_device_count": (C.c_int, []),
     "mm_index_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Elements), C.c_int32, C.c_size_t, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "mm_index_destroy": (None, [C.c_void_p]),

@@ -4,6 +4,7 @@
 // acts together with -m) is the reference's "slow" side channel: the per-hit element sets come
 // back from the device and the multiset bookkeeping of printReadStats/rescue (mmannot.cpp:474-509) is done here.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -13,7 +14,10 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <mutex>
+#include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -103,6 +107,8 @@ int main(int argc, char **argv) {
   unsigned upstream = 1000, downstream = 1000, n_threads = 1;
   bool progress = false;
   int device = 0;
+  bool device_given = false;
+  std::vector<int> devices;
   std::string gtf, output, config = "config.txt", read_stats_file, interval_stats_file;
   std::vector<std::string> reads, names;
   if (argc == 1) { usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_SUCCESS; }
@@ -168,7 +174,8 @@ int main(int argc, char **argv) {
     else if (s == "-h") { usage(overlap, upstream, downstream, rescue_threshold, n_threads); return EXIT_SUCCESS; }
     // extensions (not in the reference): device selection and the verbatim-strand compatibility switch
     else if (s == "--selftest-rand") { GlibcRand g; const int n = std::stoi(next()); for (int k = 0; k < n; ++k) std::cout << g.next() << "\n"; return EXIT_SUCCESS; }
-    else if (s == "--device") device = std::stoi(next());
+    else if (s == "--device") { device = std::stoi(next()); device_given = true; }
+    else if (s == "--devices") { std::stringstream ss(next()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(std::stoi(tok)); }
     else if (s == "--compat-strand") {
       s = next();
       if (s == "plus" || s == "const1") strand_compat = MM_STRAND_COMPAT_PLUS;
@@ -227,29 +234,38 @@ int main(int argc, char **argv) {
   }
   std::cerr << mm_annotation_log(an);
   t_annot = secs(t_start, now());
-  mm_index *index = nullptr;
+  // devices: --device d (one), --devices a,b,.. (several); with -t n > 1 and neither given, every visible device takes files
+  if (devices.empty()) {
+    if (device_given || n_threads <= 1 || n_inputs <= 1) devices.push_back(device);
+    else { const int nd = std::max(1, mm_device_count()); for (int d = 0; d < nd; ++d) devices.push_back(d); }
+  }
+  if (devices.size() > n_inputs) devices.resize(std::max<size_t>(1, n_inputs));
+  std::vector<mm_index *> indices;
   { const auto t0 = now();
-  if (mm_index_from_annotation(&index, an, device, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+  for (int d : devices) {
+    mm_index *ix = nullptr;
+    if (mm_index_from_annotation(&ix, an, d, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    indices.push_back(ix);
+  }
   t_index = secs(t0, now()); }
   mm_options opt;
   opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
   opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0; opt.defer_ratio = 0;
-  mm_ctx *ctx = nullptr;
-  if (mm_ctx_create(&ctx, index, &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
   const int32_t E = mm_annotation_n_elements(an);
   std::vector<std::string> elem_names;
   for (int32_t e = 0; e < E; ++e) elem_names.push_back(mm_annotation_element_name(an, e));
 
   std::map<uint64_t, std::vector<unsigned>> table;  // element set -> one column per input (TableCount::regionCounts, :1858)
   const size_t BATCH = 1 << 22;
-  std::vector<mm_aln> aln(BATCH);
-  std::vector<uint32_t> nh(BATCH);
-  std::vector<uint64_t> hm;
-  for (size_t fi = 0; fi < n_inputs; ++fi) {
-    if (mm_reset(ctx) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+  // One input file on one context.  `err` is std::cerr itself when files are taken one after the other, and a buffer that is
+  // printed in command-line order afterwards when several are in flight (-t): the reference's threads interleave their
+  // messages as they come; here the text is always the one a -t 1 run prints.
+  std::mutex table_mu;
+  auto process_file = [&](size_t fi, mm_ctx *ctx, std::ostream &err, std::vector<mm_aln> &aln, std::vector<uint32_t> &nh, std::vector<uint64_t> &hm) -> int {
+    if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
-    if (rc != MM_OK) { std::cerr << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+    if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
     // host bookkeeping for -m / -M / -y random
     std::unordered_map<uint32_t, PendingRead> pending;
     std::map<uint64_t, double> host_counts;
@@ -295,25 +311,24 @@ int main(int argc, char **argv) {
       size_t n = 0;
       const auto t0 = now();
       rc = mm_reader_next(rd, aln.data(), nh.data(), BATCH, &n);
-      std::cerr << mm_reader_take_log(rd);
-      if (rc != MM_OK) { std::cerr << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+      err << mm_reader_take_log(rd);
+      if (rc != MM_OK) { err << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
       const auto t1 = now();
-      t_decode += secs(t0, t1);
+      { std::lock_guard<std::mutex> lk(table_mu); t_decode += secs(t0, t1); n_records += n; }
       if (n == 0) break;
-      n_records += n;
       if (mm_annotate_batch(ctx, aln.data(), nh.data(), n, mm_reader_qid_bound(rd), 0) != MM_OK || mm_sync(ctx) != MM_OK) {
-        std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
+        err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
       }
-      t_device += secs(t1, now());
+      { std::lock_guard<std::mutex> lk(table_mu); t_device += secs(t1, now()); }
       if (host_book) {
         hm.resize(n);
-        if (mm_get_hit_masks(ctx, hm.data(), n) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        if (mm_get_hit_masks(ctx, hm.data(), n) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
         size_t hi_total = 0;
         if (interval_stats) {
           hi_cnt.resize(n);
-          if (mm_get_hit_intervals(ctx, hi_cnt.data(), nullptr, 0, &hi_total) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+          if (mm_get_hit_intervals(ctx, hi_cnt.data(), nullptr, 0, &hi_total) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
           hi_idx.resize(hi_total ? hi_total : 1);
-          if (hi_total && mm_get_hit_intervals(ctx, hi_cnt.data(), hi_idx.data(), hi_total, &hi_total) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+          if (hi_total && mm_get_hit_intervals(ctx, hi_cnt.data(), hi_idx.data(), hi_total, &hi_total) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
         }
         size_t hi_off = 0;
         for (size_t i = 0; i < n; ++i) {
@@ -365,10 +380,10 @@ int main(int argc, char **argv) {
         }
       }
       cpt += n;
-      if (progress && n_threads == 1) std::cerr << "\t" << commas(cpt) << " lines read.\r" << std::flush;
+      if (progress && n_threads == 1) err << "\t" << commas(cpt) << " lines read.\r" << std::flush;
     }
-    std::cerr << "\t" << commas(mm_reader_n_reads(rd)) << " lines read, done." << std::endl;
-    if (mm_finalize(ctx) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    err << "\t" << commas(mm_reader_n_reads(rd)) << " lines read, done." << std::endl;
+    if (mm_finalize(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     uint64_t st[MM_N_STATS];
     mm_get_stats(ctx, st);
     std::vector<uint64_t> masks;
@@ -389,13 +404,13 @@ int main(int argc, char **argv) {
       size_t nr = 0;
       mm_get_rows(ctx, nullptr, nullptr, 0, &nr);
       masks.resize(nr); sums.resize(nr);
-      if (nr && mm_get_rows(ctx, masks.data(), sums.data(), nr, &nr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+      if (nr && mm_get_rows(ctx, masks.data(), sums.data(), nr, &nr) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     }
     // Counter::dump, :1806-1818
-    std::cerr << "Results for " << reads[fi] << ":" << std::endl;
-    if (st[MM_STAT_HITS] == 0) std::cerr << "\tNo hit." << std::endl;
+    err << "Results for " << reads[fi] << ":" << std::endl;
+    if (st[MM_STAT_HITS] == 0) err << "\tNo hit." << std::endl;
     else {
-      std::cerr << "\t# reads:                       " << commas(st[MM_STAT_READS]) << "\n"
+      err << "\t# reads:                       " << commas(st[MM_STAT_READS]) << "\n"
                 << stat_line(st[MM_STAT_UNIQUE], "# uniquely mapped reads:       ", st[MM_STAT_READS])
                 << stat_line(st[MM_STAT_RESCUED], "# multi-mapping rescued reads: ", st[MM_STAT_READS])
                 << "\t# hits:                        " << commas(st[MM_STAT_HITS]) << "\n"
@@ -423,13 +438,53 @@ int main(int argc, char **argv) {
       }
       if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n";
     }
-    for (size_t r = 0; r < masks.size(); ++r) {          // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
-      auto &col = table[masks[r]];
-      if (col.empty()) col.assign(n_inputs, 0);
-      col[fi] = mm_round_to_uint(sums[r]);
+    {
+      std::lock_guard<std::mutex> lk(table_mu);
+      for (size_t r = 0; r < masks.size(); ++r) {        // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
+        auto &col = table[masks[r]];
+        if (col.empty()) col.assign(n_inputs, 0);
+        col[fi] = mm_round_to_uint(sums[r]);
+      }
     }
     mm_reader_close(rd);
+    return 0;
+  };
+  const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t) n_threads, n_inputs));
+  int rc_all = 0;
+  if (n_workers == 1) {
+    std::vector<mm_aln> aln(BATCH);
+    std::vector<uint32_t> nh(BATCH);
+    std::vector<uint64_t> hm;
+    mm_ctx *ctx = nullptr;
+    if (mm_ctx_create(&ctx, indices[0], &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, ctx, std::cerr, aln, nh, hm);
+    mm_ctx_destroy(ctx);
+  } else {
+    // -t n: the reference runs n threads over the input files (mmannot.cpp:2117-2143); here n files are in flight, each on its
+    // own context, spread over the devices
+    std::vector<std::ostringstream> errs(n_inputs);
+    std::vector<int> rcs(n_inputs, 0);
+    std::atomic<size_t> next_file(0);
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < n_workers; ++w)
+      workers.emplace_back([&, w]() {
+        std::vector<mm_aln> aln(BATCH);
+        std::vector<uint32_t> nh(BATCH);
+        std::vector<uint64_t> hm;
+        mm_ctx *ctx = nullptr;
+        const bool ok = mm_ctx_create(&ctx, indices[w % indices.size()], &opt, nullptr) == MM_OK;
+        for (;;) {
+          const size_t fi = next_file.fetch_add(1);
+          if (fi >= n_inputs) break;
+          if (!ok) { errs[fi] << "mmannot-amd: " << mm_last_error() << std::endl; rcs[fi] = EXIT_FAILURE; continue; }
+          rcs[fi] = process_file(fi, ctx, errs[fi], aln, nh, hm);
+        }
+        if (ctx) mm_ctx_destroy(ctx);
+      });
+    for (auto &t : workers) t.join();
+    for (size_t fi = 0; fi < n_inputs; ++fi) { std::cerr << errs[fi].str(); if (rcs[fi]) rc_all = rcs[fi]; }
   }
+  if (rc_all) return rc_all;
   // TableCount::dump, :1877-1900
   std::vector<uint64_t> keys;
   for (auto &e : table) keys.push_back(e.first);
@@ -446,7 +501,8 @@ int main(int argc, char **argv) {
   out.flush();
   if (read_stats) read_stats_out.close();
   if (interval_stats) interval_stats_out.close();
-  mm_ctx_destroy(ctx); mm_index_destroy(index); mm_annotation_free(an);
+  for (mm_index *ix : indices) mm_index_destroy(ix);
+  mm_annotation_free(an);
   std::cerr << "Successfully done." << std::endl;
   if (timing) {
     const double total = secs(t_start, now());

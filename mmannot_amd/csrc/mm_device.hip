@@ -60,6 +60,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 extern "C" const char *mm_last_error(void) { return g_err.c_str(); }
 extern "C" const char *mm_version(void) { return MM_VERSION; }
+extern "C" int mm_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 // ----------------------------------------------------------------------------- device structures
 #define GT_CAP (1u << 16)          // global element-set table (distinct rows of the count table)

@@ -78,3 +78,20 @@ def test_cli_two_input_files(gpu_lib, inputs, tmp_path):
     assert p.returncode == c["rc"]
     assert p.stdout.decode() == c["stdout"]
     assert p.stderr.decode().replace(d2, "$E").replace(d, "$D") == c["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["-t", "2"], ["-t", "2", "--devices", "0,0"], ["-t", "5", "--device", "0"]])
+def test_cli_files_in_flight(gpu_lib, inputs, tmp_path, extra):
+    """-t n: n input files in flight on their own contexts (spread over --devices); table and messages are those of a -t 1 run,
+    columns in command-line order whatever the completion order."""
+    from oracle import gen_synth_golden as g
+    c = CASES["tair10_two_files"]
+    d, gtf, cfg, bam = inputs["tair10"]
+    d2 = str(tmp_path)
+    _, _, bam2 = g.make_inputs(c["workload2"], d2)
+    p = subprocess.run([CLI, "-a", gtf, "-c", cfg, "-s", "F", "-r", bam, bam2, "-n", "first", "second"] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == c["rc"], p.stderr.decode()
+    assert p.stdout.decode() == c["stdout"]
+    assert p.stderr.decode().replace(d2, "$E").replace(d, "$D") == c["stderr"]
