@@ -139,6 +139,29 @@ def test_name_grouped_input(gpu_lib, oracle):
     index.close()
 
 
+@pytest.mark.parametrize("shuffle", [True, False])
+def test_huge_nh_payload_by_index(gpu_lib, oracle, shuffle):
+    """A batch holding an NH >= 65535 cannot carry (slot, NH) in 32 bits: the sort payload becomes the record index and the
+    merge kernel reads the element set and NH through it (INFO_BIGNH).  Same answers as the oracle, in interleaved and in
+    name-grouped order, across batches with and without such a record."""
+    mm = gpu_lib
+    rng = np.random.default_rng(4242)
+    desc = sr.random_config(rng, n_lines=5, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=2000, maxpos=100000)
+    reads = sr.random_reads(rng, ix, n=24000, nchr=3, maxpos=100000, nh_max=6, shuffle=shuffle)
+    nh = reads["nh"].copy()
+    q = reads["qid"]
+    for name, val in ((int(q[100]), 70000), (int(q[9000]), 65535), (int(q[17000]), 4000000000)):   # whole names get the huge value
+        nh[q == name] = val
+    reads = dict(reads, nh=nh)
+    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy="default")
+    cfg = to_cfg(mm, desc)
+    for batches in (1, 3):
+        r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="F", strategy="default", batches=batches, keep=False)
+        assert r["stats"] == ref.stats
+        assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+
+
 def test_empty_and_edge_batches(gpu_lib, oracle):
     mm = gpu_lib
     rng = np.random.default_rng(77)
