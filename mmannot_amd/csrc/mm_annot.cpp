@@ -12,6 +12,7 @@
 #include <regex>
 #include <sstream>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -44,20 +45,33 @@ struct ConfigModel {
     return r;
   }
 
-  // first flattened Order entry whose source regex fully matches and whose type is empty or equal
+  // first flattened Order entry whose source regex fully matches and whose type is empty or equal.  A GTF has millions of
+  // lines but a few dozen distinct (source, type) pairs: the regex matches run once per pair.
+  mutable std::unordered_map<std::string, long> order_cache;
+  mutable std::unordered_map<std::string, std::string> translate_cache;
   long order_of(const std::string &source, const std::string &type) const {
-    long n = 0;
+    std::string key;
+    key.reserve(source.size() + type.size() + 1);
+    key += source; key += '\t'; key += type;
+    auto it = order_cache.find(key);
+    if (it != order_cache.end()) return it->second;
+    long found = -1, n = 0;
     for (const auto &ln : lines) {
-      for (size_t i = 0; i < ln.size(); ++i)
-        if (std::regex_match(source, ln[i].re) && (ln[i].type.empty() || ln[i].type == type)) return n + (long) i;
+      for (size_t i = 0; i < ln.size() && found < 0; ++i)
+        if (std::regex_match(source, ln[i].re) && (ln[i].type.empty() || ln[i].type == type)) found = n + (long) i;
+      if (found >= 0) break;
       n += (long) ln.size();
     }
-    return -1;
+    order_cache.emplace(std::move(key), found);
+    return found;
   }
-  std::string translate(const std::string &s) const {
+  const std::string &translate(const std::string &s) const {
+    auto it = translate_cache.find(s);
+    if (it != translate_cache.end()) return it->second;
+    std::string out = s;
     for (const auto &sy : synonyms)
-      if (std::regex_match(s, sy.first)) return sy.second;
-    return s;
+      if (std::regex_match(s, sy.first)) { out = sy.second; break; }
+    return translate_cache.emplace(s, std::move(out)).first->second;
   }
   static long rule_of(const std::vector<Rule> &rs, const std::string &source, const std::string &type, bool second) {
     for (const auto &r : rs)
@@ -164,53 +178,70 @@ struct ConfigModel {
 
 // ------------------------------------------------------------------ GTF record
 struct GtfRecord {
+  // Views into the line being parsed (valid while that line is): a GTF has millions of lines, and the map of
+  // vector-of-strings this used to build per line was most of the loading time.
   std::string chromosome, source, type;
   uint64_t start = 0, end = 0;
   int strand = MM_STRAND_R;
-  std::unordered_map<std::string, std::vector<std::string>> tags;
+  struct Tag { std::string_view key, value; };
+  std::vector<Tag> tags;       // a later occurrence of a key replaces an earlier one (map assignment in the reference)
   bool ok = false;
 
-  bool has(const char *k) const { return tags.find(k) != tags.end(); }
-  const std::string &first(const char *k) const {
-    static const std::string empty;
-    auto it = tags.find(k);
-    return (it == tags.end() || it->second.empty()) ? empty : it->second.front();
+  const Tag *find(const char *k) const {
+    const std::string_view kv(k);
+    for (size_t i = tags.size(); i-- > 0;) if (tags[i].key == kv) return &tags[i];
+    return nullptr;
   }
+  bool has(const char *k) const { return find(k) != nullptr; }
+  // first element of the comma-separated value ("" when the value is empty)
+  std::string first(const char *k) const {
+    const Tag *t = find(k);
+    if (!t) return std::string();
+    return std::string(t->value.substr(0, t->value.find(',')));
+  }
+  static void ltrim_v(std::string_view &v) { size_t i = 0; while (i < v.size() && std::isspace((unsigned char) v[i])) ++i; v.remove_prefix(i); }
+  static void rtrim_v(std::string_view &v) { size_t n = v.size(); while (n > 0 && std::isspace((unsigned char) v[n - 1])) --n; v = v.substr(0, n); }
 
   explicit GtfRecord(const std::string &line) {
-    std::vector<std::string> col;
-    split_all(line, '\t', col);
-    if (col.size() != 9) return;  // the reference asserts here (mmannot.cpp:526)
-    chromosome = col[0]; source = col[1]; type = col[2];
+    // getline-style split at tabs: a trailing empty field is not produced
+    std::string_view col[10];
+    size_t nc = 0, p0 = 0;
+    const std::string_view lv(line);
+    while (p0 < lv.size() && nc < 10) {
+      const size_t t = lv.find('\t', p0);
+      if (t == std::string_view::npos) { col[nc++] = lv.substr(p0); p0 = lv.size(); break; }
+      col[nc++] = lv.substr(p0, t - p0);
+      p0 = t + 1;
+    }
+    if (nc != 9 || p0 < lv.size()) return;  // the reference asserts here (mmannot.cpp:526)
+    chromosome.assign(col[0]); source.assign(col[1]); type.assign(col[2]);
     strand = (col[6] == "+") ? MM_STRAND_F : MM_STRAND_R;
-    try { start = std::stoul(col[3]); end = std::stoul(col[4]); } catch (...) { return; }
-    std::string rem = col[8];
-    trim(rem);
+    try { start = std::stoul(std::string(col[3])); end = std::stoul(std::string(col[4])); } catch (...) { return; }
+    std::string_view rem = col[8];
+    ltrim_v(rem); rtrim_v(rem);
     // attribute grammar: key, then blank or '=', then a "quoted" or bare value, up to ';'
     while (!rem.empty()) {
       const size_t sp = rem.find(' '), eq = rem.find('=');
-      const size_t cut = (eq == std::string::npos) ? sp : ((sp == std::string::npos) ? eq : std::min(sp, eq));
-      std::string tag = rem.substr(0, cut), value;
-      rtrim(tag);
-      rem = rem.substr(cut + 1);  // cut == npos wraps to 0: the text is kept, as in the reference
-      ltrim(rem);
+      const size_t cut = (eq == std::string_view::npos) ? sp : ((sp == std::string_view::npos) ? eq : std::min(sp, eq));
+      std::string_view tag = rem.substr(0, cut), value;
+      rtrim_v(tag);
+      if (cut != std::string_view::npos) rem.remove_prefix(cut + 1);  // no separator at all: the text is kept, as in the reference
+      ltrim_v(rem);
       if (!rem.empty() && rem[0] == '"') {
-        rem = rem.substr(1);
+        rem.remove_prefix(1);
         const size_t q = rem.find('"');
         value = rem.substr(0, q);
-        rem = rem.substr(q + 1);
+        if (q != std::string_view::npos) rem.remove_prefix(q + 1);   // an unterminated quote keeps the text, as in the reference
       } else {
         size_t sc = rem.find(';');
-        if (sc == std::string::npos) sc = rem.size();
+        if (sc == std::string_view::npos) sc = rem.size();
         value = rem.substr(0, sc);
-        rtrim(value);
+        rtrim_v(value);
       }
-      std::vector<std::string> values;
-      split_all(value, ',', values);
-      tags[tag] = values;
+      tags.push_back(Tag{tag, value});
       const size_t semi = rem.find(';');
-      if (semi == std::string::npos) rem.clear();
-      else { rem = rem.substr(semi + 1); ltrim(rem); }
+      if (semi == std::string_view::npos) rem = std::string_view();
+      else { rem.remove_prefix(semi + 1); ltrim_v(rem); }
     }
     ok = true;
   }
