@@ -1,0 +1,21 @@
+#!/bin/bash
+# Host code (config/GTF builder, reads decoder, table finalisation) under AddressSanitizer + UBSan, or ThreadSanitizer, through the
+# CPU tests.  Sanitizers cover host code only: GPU ASan is not available on this pool.
+#   bash tools/sanitize_host.sh [address|thread]
+set -e
+cd "$(dirname "$0")/.."
+KIND=${1:-address}
+OUT=$(mktemp -d /tmp/mmsan.XXXXXX)
+cat > "$OUT/stub.cpp" <<'EOS'
+#include "mmannot_amd.h"
+// the device half of the library is not part of this build
+extern "C" int mm_index_create(mm_index **, const mm_elements *, int32_t, size_t, const int32_t *, const int32_t *, const int32_t *, const uint8_t *, const uint8_t *, int, int) { return MM_ERR_HIP; }
+extern "C" const char *mm_last_error(void) { return "device code not built"; }
+EOS
+if [ "$KIND" = thread ]; then SAN="-fsanitize=thread"; RT=$(g++ -print-file-name=libtsan.so); TESTS="tests/test_decoder.py";
+else SAN="-fsanitize=address,undefined"; RT=$(g++ -print-file-name=libasan.so); TESTS="tests/test_decoder.py tests/test_builder.py tests/test_kat.py tests/test_synth_e2e.py tests/test_addnh.py"; fi
+g++ -std=c++17 -g -O1 $SAN -fno-omit-frame-pointer -shared -fPIC -I include -o "$OUT/libmm_host_san.so" \
+    mmannot_amd/csrc/mm_annot.cpp mmannot_amd/csrc/mm_reads.cpp mmannot_amd/csrc/mm_host.cpp "$OUT/stub.cpp" -lz -lpthread
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 TSAN_OPTIONS="report_signal_unsafe=0" MMANNOT_AMD_LIB="$OUT/libmm_host_san.so" \
+    python -m pytest $TESTS -x -q -m "not gpu"
+rm -rf "$OUT"
