@@ -222,8 +222,9 @@ class Counter:
 
     PHASES = ("h2d", "probe", "compact", "sort", "merge", "flush")
 
-    def set_profiling(self, on: bool):
-        check(lib().mm_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False/0 off, True/1 every phase, 2 the probe phase only."""
+        check(lib().mm_set_profiling(self._h, int(on)))
 
     def phase_ms(self):
         ms = (C.c_double * 6)()

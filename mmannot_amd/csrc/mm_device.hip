@@ -1501,7 +1501,7 @@ struct mm_ctx {
   struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr; size_t n = 0; };
   std::vector<Run> runs;
   // optional live timing (HIP events on the context's stream), see mm_set_profiling
-  bool profiling = false;
+  int profiling = 0;   // 0 off, 1 every phase, 2 the probe phase only
   struct Span { int phase; hipEvent_t a, b; };
   std::vector<Span> spans;
 };
@@ -1512,7 +1512,8 @@ struct PhaseTimer {  // records an event pair around a group of launches when pr
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
   hipStream_t stream_override = nullptr;
   PhaseTimer(mm_ctx *c_, int ph) : c(c_), phase(ph) {
-    if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void) hipEventRecord(a, c->stream);
+    if ((c->profiling == 1 || (c->profiling == 2 && ph == MM_PHASE_PROBE)) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+      (void) hipEventRecord(a, c->stream);
   }
   void restart() { if (a) (void) hipEventRecord(a, stream_override ? stream_override : c->stream); }
   void stop() {
@@ -2077,7 +2078,7 @@ extern "C" int mm_set_profiling(mm_ctx *c, int on) {
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
   c->spans.clear();
-  c->profiling = on != 0;
+  c->profiling = (on == 2) ? 2 : (on != 0 ? 1 : 0);
   return MM_OK;
 }
 
