@@ -259,8 +259,21 @@ struct NameDict {
   }
   void prefetch(uint32_t h) const { if (mask) __builtin_prefetch(&table[h & mask]); }
   uint32_t get(const char *p, size_t n) { return get(p, n, (uint32_t) hash(p, n)); }
+  // Names seen a moment ago (the other hits of a multi-mapping read are usually close by in the file) are answered from a small
+  // direct-mapped cache that holds the name itself: one cache line instead of table slot + name_off + arena.
+  struct Recent { uint32_t hash, id; uint8_t len; char name[55]; };
+  static constexpr size_t RECENT = 4096;
+  std::vector<Recent> recent;
   uint32_t get(const char *p, size_t n, uint32_t h) {
     if (last != 0xFFFFFFFFu && same(last, p, n)) return last;
+    if (recent.empty()) { recent.resize(RECENT); for (Recent &r : recent) { r.hash = 0; r.id = 0xFFFFFFFFu; r.len = 0; } }
+    Recent &rc = recent[(h >> 7) & (RECENT - 1)];
+    if (rc.id != 0xFFFFFFFFu && rc.hash == h && rc.len == n && memcmp(rc.name, p, n) == 0) return last = rc.id;
+    const uint32_t id = lookup(p, n, h);
+    if (n <= sizeof(rc.name)) { rc.hash = h; rc.id = id; rc.len = (uint8_t) n; memcpy(rc.name, p, n); }
+    return last = id;
+  }
+  uint32_t lookup(const char *p, size_t n, uint32_t h) {
     if ((name_off.size() + 1) * 2 > table.size()) grow();
     size_t s = h & mask;
     for (;;) {

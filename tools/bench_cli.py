@@ -47,7 +47,7 @@ def main():
                            env=dict(os.environ, MM_CLI_TIMING="1"))
         dt = time.perf_counter() - t0
         for line in p.stderr.decode().splitlines():
-            if line.startswith("[mmannot-amd timing]"):
+            if line.startswith("[mmannot-amd timing]") or line.startswith("[reader]"):
                 print("   ", line)
         res[name] = (dt, open(out).read() if p.returncode == 0 else p.stderr.decode()[-300:])
         print(f"{name}: {dt:.2f} s wall, {n / dt / 1e6:.2f} M records/s end to end (rc {p.returncode})")
