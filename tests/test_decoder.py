@@ -82,7 +82,7 @@ def test_fast_record_path_equals_general_parser(oracle, tmp_path, monkeypatch):
     rng = np.random.default_rng(11)
     fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
     recs = []
-    for i in range(20000):
+    for i in range(120000):                      # long enough for the framed runs to reach the parser threads (>= 8192 records)
         ops = [("MIDS=X"[int(rng.integers(0, 6))], int(rng.integers(1, 90))) for _ in range(int(rng.integers(0, 4)))]
         tags = b""
         for _ in range(int(rng.integers(0, 5))):
@@ -98,7 +98,9 @@ def test_fast_record_path_equals_general_parser(oracle, tmp_path, monkeypatch):
             else:
                 tags += struct.pack(fmt[t], int(rng.integers(0, 100)))
         recs.append(oracle._bam_record(int(rng.integers(-1, 2)), int(rng.integers(0, 90000)), int(rng.integers(0, 2)) * 16,
-                                       "r%d" % int(rng.integers(0, 4000)), ops, int(rng.integers(0, 3)) * 25, tags))
+                                       "r%d" % int(rng.integers(0, 24000)), ops, int(rng.integers(0, 3)) * 25, tags))
+        if i % 9973 == 9972:                     # now and then a record only the general parser takes (N in the CIGAR, XA)
+            recs.append(oracle._bam_record(0, 500 + i, 0, "odd%d" % i, [("M", 10), ("N", 100), ("M", 10)], 0, b"NMC\x01XAZchr1,+77,20M,1;\0"))
     chroms = [("chr1", 100000), ("chrZ", 50000)]
     p0, p1 = str(tmp_path / "s.bam"), str(tmp_path / "sb.bam")
     oracle.write_bam(p0, chroms, recs)
