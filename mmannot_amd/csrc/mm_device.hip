@@ -90,13 +90,28 @@ __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits need
   while (b < 32 && (1ull << b) <= (unsigned long long) span) ++b;
   return b;
 }
-// sort-key width of this batch: multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys)
-__device__ __forceinline__ int batch_key_bits(const unsigned int *info, int fixed_bits) {
-  if (fixed_bits) return fixed_bits;
-  if (!info[INFO_UNSORTED]) return 1;   // already grouped by name: the compacting first pass is all that is needed
-  const unsigned int qmin = ~info[INFO_QINV], qmax = info[INFO_QMAX];
-  return qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
+// Sort layout of this batch.  Multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys).  The key's
+// bits are split evenly over the passes an 8-bit layout would need - 21 bits are sorted as 3 x 7, not 8 + 8 + 5: fewer
+// digits per pass mean longer runs per digit inside a tile, i.e. longer contiguous segments in the scatter's writes.
+struct SortLayout { int passes; u32 width; };
+__device__ __forceinline__ SortLayout batch_layout(const unsigned int *info, int fixed_bits) {
+  int bits = fixed_bits;
+  if (!bits) {
+    const unsigned int qmin = ~info[INFO_QINV], qmax = info[INFO_QMAX];
+    bits = qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
+  }
+  SortLayout L;
+  L.passes = (bits + 7) / 8;
+  L.width = (u32) ((bits + L.passes - 1) / L.passes);
+  return L;
 }
+// passes this batch really runs: one (the compacting first pass) when the records are already grouped by name
+__device__ __forceinline__ int batch_passes(const unsigned int *info, int fixed_bits) {
+  if (!fixed_bits && !info[INFO_UNSORTED]) return 1;
+  return batch_layout(info, fixed_bits).passes;
+}
+// digit of key k in the pass the host launched with shift = 8 * pass
+__device__ __forceinline__ u32 batch_digit(u32 k, const SortLayout L, int shift) { return (k >> ((u32) (shift >> 3) * L.width)) & ((1u << L.width) - 1u); }
 
 struct GlobalTable {
   u64 *key;      // 0 = empty (an element set is never empty)
@@ -658,7 +673,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   __shared__ u32 h[256];
   __shared__ u32 segF[RS_ROUNDS * 4], segL[RS_ROUNDS * 4];
   __shared__ u32 tileCnt, tileBad;
-  if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
+  if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
+  const SortLayout L = batch_layout(info, fixed_bits);
   const bool order = FIRST && rebase;
   // (the check stops at the first inversion: this wave's, or one another tile has already published)
   bool chk = order && ((volatile u32 *) info)[INFO_UNSORTED] == 0;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
     const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
     u32 k = 0, v;
     const bool ok = rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v);
-    wave_hist_add(h, (k >> shift) & 255u, ok, fixed_bits != 0);
+    wave_hist_add(h, batch_digit(k, L, shift), ok, fixed_bits != 0);
     if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
       const u64 below = vm & ((1ull << lane) - 1ull);
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
   __shared__ u32 wsum[4];
   __shared__ u32 carry;
   __shared__ u32 isLast;
-  if (shift > 0 && shift >= batch_key_bits(info, fixed_bits)) return;
+  if (shift > 0 && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
   u32 *row = hist + (size_t) blockIdx.x * nblk;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -815,13 +831,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   __shared__ u32 goff[256];      // global position of digit d's first pair of this tile, minus its tile-local offset
   __shared__ u32 wsum[4];
   __shared__ u32 tcountS;
-  if (!FIRST && shift >= batch_key_bits(info, fixed_bits)) return;
+  if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
+  const SortLayout L = batch_layout(info, fixed_bits);
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const size_t lim = FIRST ? n : (size_t) info[INFO_M];
   if (lo >= lim) return;
   // name-grouped input (see k_rs_hist): one "digit" for everything, i.e. a stable compaction in file order
   const bool presorted = FIRST && rebase && !info[INFO_UNSORTED];
-  const u32 dmask = presorted ? 0u : 255u;
+  const u32 dmask = presorted ? 0u : 255u;   // (presorted: every pair in "digit" 0)
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   cntw[0][t] = 0; cntw[1][t] = 0; cntw[2][t] = 0; cntw[3][t] = 0;
   __syncthreads();
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     if (presorted) {   // (wave-uniform) all pairs count for digit 0: one add per wave instead of 64 colliding atomics
       const u32 c = (u32) __popcll(__ballot(ok));
       if (lane == 0) cntw[w][0] += c;
-    } else wave_hist_add(cntw[w], (kreg[r] >> shift) & 255u, ok, fixed_bits != 0);
+    } else wave_hist_add(cntw[w], batch_digit(kreg[r], L, shift), ok, fixed_bits != 0);
   }
   __syncthreads();
   if (presorted) {   // plain ordered compaction: the pairs go straight from the registers to their place, in file order
@@ -873,7 +890,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {  // C: wave-private, LDS operations of one wave execute in program order
     const bool valid = (vmask >> r) & 1u;
-    const u32 d = (kreg[r] >> shift) & dmask;
+    const u32 d = batch_digit(kreg[r], L, shift) & dmask;
     u64 peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -890,7 +907,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   const u32 tcount = tcountS;
   for (u32 i = t; i < tcount; i += RS_THREADS) {  // D
     const u32 k = lkey[i];
-    const u32 g = goff[(k >> shift) & dmask] + i;
+    const u32 g = goff[batch_digit(k, L, shift) & dmask] + i;
     kout[g] = k; vout[g] = lval[i];
   }
 }
@@ -918,7 +935,7 @@ __global__ __launch_bounds__(256) void k_chunk_default(const u32 *__restrict__ k
   const u32 M = info[INFO_M];
   const u32 qmin = ~info[INFO_QINV];
   const bool by_index = info[INFO_BIGNH] != 0;
-  const int passes = (batch_key_bits(info, 0) + 7) / 8;       // the sort ping-pongs A -> B -> A ...
+  const int passes = batch_passes(info, 0);                    // the sort ping-pongs A -> B -> A ...
   const u32 *__restrict__ skeys = (passes & 1) ? kB : kA;
   const u32 *__restrict__ svals = (passes & 1) ? vB : vA;
   const u32 lane = threadIdx.x & 63;
