@@ -93,7 +93,7 @@ def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
 def test_name_grouped_input(gpu_lib, oracle):
     """An aligner's own output keeps the hits of a read adjacent, so read-name ids are non-decreasing and the name sort is
     skipped (k_rs_hist's order check).  Same answers as the oracle, malformed groups included; and one inversion anywhere -
-    inside a wave, or across the wave (64) / round (256) / tile (4096) boundaries of the check - must send the batch down
+    inside a wave, or across the wave (64) / round (512) / tile (8192) boundaries of the check - must send the batch down
     the general path and still give the oracle's answer."""
     mm = gpu_lib
     rng = np.random.default_rng(99)
@@ -123,7 +123,7 @@ def test_name_grouped_input(gpu_lib, oracle):
             assert st == ref.stats and rows == dict(zip(ref.row_mask.tolist(), ref.row_count.astype(float).tolist()))
             assert grouped == batches
         q, nh = reads["qid"], reads["nh"]
-        for pos in (1, 37, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8191, 8192, 12288, 20990):
+        for pos in (1, 37, 63, 64, 65, 255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 16383, 16384, 20990):
             j = pos
             while j < len(q) and not (q[j] != q[j - 1] and nh[j] != 1 and nh[j - 1] != 1):
                 j += 1
