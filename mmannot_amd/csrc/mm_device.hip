@@ -685,10 +685,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   __syncthreads();
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   u32 wcnt = 0;
+  u32 kk[RS_ROUNDS], okm = 0;        // all of the thread's keys are requested before the first is used
+#pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
-    const size_t i = lo + (size_t) r * RS_THREADS + threadIdx.x;
-    u32 k = 0, v;
-    const bool ok = rs_load<FIRST>(keys, vals, info, i, n, rebase, k, v);
+    u32 v;
+    kk[r] = 0;
+    if (rs_load<FIRST>(keys, vals, info, lo + (size_t) r * RS_THREADS + threadIdx.x, n, rebase, kk[r], v)) okm |= 1u << r;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const u32 k = kk[r];
+    const bool ok = (okm >> r) & 1u;
     wave_hist_add(h, batch_digit(k, L, shift), ok, fixed_bits != 0);
     if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
