@@ -13,6 +13,6 @@ for w in "$@"; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/${w}_fetch -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${w}_fetch.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/${w}_write -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${w}_write.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/prof/${w}_l2 -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${w}_l2.log 2>&1
-  tail -n 1 gpurun_out/prof/${w}_trace.log > gpurun_out/prof/${w}_bench_under_rocprof.json
+  grep '^{"metric"' gpurun_out/prof/${w}_trace.log | tail -n 1 > gpurun_out/prof/${w}_bench_under_rocprof.json
   echo "profiled $w"
 done
