@@ -159,6 +159,41 @@ def gen_builder():
         one(f"synth_{shape}_s{seed}_d300_D50", cfgp, gtf, ["-d", "300", "-D", "50"])
         meta[f"synth_{shape}_s{seed}"]["synth"] = dict(shape=shape, seed=seed, scale=scale)
         meta[f"synth_{shape}_s{seed}_d300_D50"]["synth"] = dict(shape=shape, seed=seed, scale=scale)
+    # attribute-column syntax the GTF parser has to read the way the reference does: GFF3 style, missing quotes / semicolons,
+    # duplicate keys, comma lists, an unterminated quote, blanks around '='  (an attribute column without any separator makes
+    # the reference itself crash - SIGSEGV after "cannot deduce id" - so that case has no oracle)
+    quirks_cfg = "Introns:\nsrc:gene\nVicinity:\nsrc:gene\nOrder:\nsrc:CDS +\nsrc:5'UTR +\nsrc:3'UTR +\nsrc:featA\nsrc:featB -\nsrc:gene\nsrc:intron\nsrc:upstream,src:downstream\n"
+    rows = [
+        ("c1", "src", "featA", 1000, 1500, "+", "ID=gene1;Name=foo"),
+        ("c1", "src", "featA", 2000, 2500, "-", 'gene_id "g2"; transcript_id "t2"'),
+        ("c1", "src", "featA", 3000, 3500, "+", "gene_id g3; transcript_id t3;"),
+        ("c1", "src", "featA", 4000, 4500, "+", 'gene_id "g4a"; gene_id "g4b";'),
+        ("c1", "src", "featB", 5000, 5500, "-", "ID=a5,b5;Parent=p5,q5"),
+        ("c1", "src", "featB", 6000, 6500, "+", 'gene_id "g6; transcript_id "t6";'),
+        ("c1", "src", "featA", 8000, 8500, "+", "ID = g8 ; Parent = p8"),
+        ("c1", "src", "featA", 9000, 9500, "+", "Parent=p9.1"),
+        ("c1", "src", "featB", 9600, 9900, "-", 'transcript_id "t10" ;   gene_name "x y z";  '),
+        ("c1", "src", "gene", 20000, 26000, "+", 'gene_id "G1"; gene_name "with ; semicolon";'),
+        ("c1", "src", "transcript", 20000, 26000, "+", 'gene_id "G1"; transcript_id "T1";'),
+        ("c1", "src", "exon", 20000, 21000, "+", 'gene_id "G1"; transcript_id "T1"; exon_number "1";'),
+        ("c1", "src", "exon", 23000, 26000, "+", "Parent=T1"),
+        ("c1", "src", "CDS", 20500, 21000, "+", 'transcript_id "T1"'),
+        ("c1", "src", "CDS", 23000, 24000, "+", "Parent=G1,Tx"),
+        ("c2", "src", "gene", 500, 9000, "-", "ID=G2"),
+        ("c2", "src", "mRNA", 500, 9000, "-", "ID=T2;Parent=G2"),
+        ("c2", "src", "exon", 500, 1500, "-", "Parent=T2"),
+        ("c2", "src", "exon", 1400, 3000, "-", "Parent=T2"),
+        ("c2", "src", "exon", 8000, 9000, "-", "Parent = T2 ;"),
+        ("c2", "src", "CDS", 1000, 8500, "-", "Parent=T2"),
+        ("c2", "other", "thing", 100, 200, "+", 'gene_id "unused1";'),
+        ("c2", "src", "exon", 150, 180, "+", 'gene_id "unused1";'),
+    ]
+    quirks_gtf = "".join("\t".join([c, so, ty, str(a), str(b), ".", sd, ".", attr]) + "\n" for c, so, ty, a, b, sd, attr in rows)
+    gq = os.path.join(tmp, "quirks.gtf"); open(gq, "w").write(quirks_gtf)
+    cq = os.path.join(tmp, "quirks.cfg"); open(cq, "w").write("Synonyms:\nmRNA:transcript\n" + quirks_cfg)
+    one("quirks", cq, gq, [])
+    meta["quirks"]["gtf_text"] = quirks_gtf
+    meta["quirks"]["cfg_text"] = "Synonyms:\nmRNA:transcript\n" + quirks_cfg
     json.dump(meta, open(os.path.join(out, "cases.json"), "w"), indent=1)
 
 

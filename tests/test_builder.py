@@ -106,3 +106,18 @@ def test_config_errors(tmp_path):
         load("src:featA\n")
     a = load("Order:\nsrc:featA +\n")
     assert a.names == ["src:featA (+)"] and a.n_intervals == 1 and a.interval_id(0) == "a"
+
+
+def test_builder_attribute_quirks(tmp_path):
+    """Attribute-column syntax read the way the reference reads it (GFF3 style, missing quotes / semicolons, duplicate keys,
+    comma lists, an unterminated quote, blanks around '='): interval dump of the compiled reference on a hand-written GTF."""
+    import mmannot_amd.api as api
+    c = BCASES["quirks"]
+    assert c["rc"] == 0
+    gtf = tmp_path / "q.gtf"; gtf.write_text(c["gtf_text"])
+    cfg = tmp_path / "q.cfg"; cfg.write_text(c["cfg_text"])
+    a = api.Annotation(str(cfg), str(gtf))
+    ix = gu.load_index(os.path.join(GOLD, "builder", "index_quirks.tsv.gz"))
+    compare(a, ix)
+    assert [a.interval_id(i) for i in range(a.n_intervals)] == list(ix["id"])
+    assert a.log == c["stderr_head"]
