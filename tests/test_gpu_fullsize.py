@@ -93,3 +93,22 @@ def test_full_size(gpu_lib, oracle, name, c):
     assert stp == ref.stats
     assert np.array_equal(mp, ref.row_mask[fo]) and np.array_equal(sp.view(np.uint64), ref.row_sum[fo].view(np.uint64))
     index.close()
+
+
+def test_one_very_large_batch(gpu_lib):
+    """A single batch of 40 M alignments (more than 4096 sort tiles, so k_rs_scan loops) gives what 2^22-alignment batches give."""
+    from mmannot_amd import synth
+    mm = gpu_lib
+    an = synth.synth_annotation("hs38", seed=3, scale=0.5)
+    cfg = mm.Config.from_json(an.config)
+    index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes)
+    chr_len = np.ascontiguousarray(an.chr_len, dtype=np.int64)
+    kw = dict(total=40_000_000, seed=77, read_len=100, nh_max=20, scatter=16, chr_len=chr_len, strategy="default")
+    m1, s1, st1 = run_stream(mm, index, cfg, batch=40_000_000, **kw)
+    m2, s2, st2 = run_stream(mm, index, cfg, batch=1 << 22, **kw)
+    assert st1 == st2 and np.array_equal(m1, m2) and np.array_equal(s1, s2)
+    kw = dict(kw, strategy="ratio", nh_max=100)
+    m1, s1, st1 = run_stream(mm, index, cfg, batch=40_000_000, **kw)
+    m2, s2, st2 = run_stream(mm, index, cfg, batch=1 << 22, **kw)
+    assert st1 == st2 and np.array_equal(m1, m2) and np.array_equal(s1.view(np.uint64), s2.view(np.uint64))
+    index.close()
