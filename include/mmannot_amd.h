@@ -76,21 +76,35 @@ typedef struct mm_options {
   int32_t defer_ratio;    /* -y ratio only: park each batch's ordered accumulation until mm_ratio_resolve (multi-GPU chaining) */
 } mm_options;
 
-/* One Read as handed to scan() (class Read, mmannot.cpp:846-903), 16 bytes.
+/* One Read as handed to scan() (class Read, mmannot.cpp:846-903): 16 bytes, the whole per-alignment input stream
+ * ("stream in: 16 B").
  *   start = record.start = pos0+1 (mmannot.cpp:1537), end after parseCigar (mmannot.cpp:852-875,
  *   may be start-1 for a record without CIGAR operations).
- *   tid_strand bit 0  = record.strand (1 when flag 0x10 is clear, mmannot.cpp:608)
- *              bits 31..1 = index into the *annotation's* chromosome table + 1; 0 = the read's
- *              chromosome is unknown to the annotation (mmannot.cpp:1293-1302).
- *   qid = dense id of the read name (the reference keys readCounts on the string, mmannot.cpp:1671).
- * NH (record.nHits, mmannot.cpp:1560, 1637-1641) travels in a parallel uint32 array; NULL = all 1. */
+ *   tsn  bit 0       = record.strand (1 when flag 0x10 is clear, mmannot.cpp:608)
+ *        bits 11..1  = record.nHits (NH; mmannot.cpp:1560, 1637-1641) when it is 0..2046; MM_ALN_NH_ESCAPE (2047) = the value
+ *                      is in the batch's mm_nh_big side list (an aligner reporting more than 2046 hits of one read is rare)
+ *        bits 31..12 = index into the *annotation's* chromosome table + 1; 0 = the read's chromosome is unknown to the
+ *                      annotation (mmannot.cpp:1293-1302).  At most MM_ALN_MAX_CHROMOSOMES chromosomes.
+ *   qid = dense id of the read name (the reference keys readCounts on the string, mmannot.cpp:1671). */
 typedef struct mm_aln {
   int32_t start;
   int32_t end;
-  uint32_t tid_strand;
+  uint32_t tsn;
   uint32_t qid;
 } mm_aln;
-#define MM_ALN_TID_STRAND(tid, strand_plus) ((((uint32_t) ((tid) + 1)) << 1) | ((strand_plus) ? 1u : 0u))
+#define MM_ALN_NH_BITS 11
+#define MM_ALN_NH_ESCAPE ((1u << MM_ALN_NH_BITS) - 1u)
+#define MM_ALN_MAX_CHROMOSOMES ((1 << (31 - MM_ALN_NH_BITS)) - 2)
+#define MM_ALN_PACK(tid, strand_plus, nh) \
+  ((((uint32_t) ((tid) + 1)) << (MM_ALN_NH_BITS + 1)) | ((((uint32_t) (nh)) < MM_ALN_NH_ESCAPE ? (uint32_t) (nh) : MM_ALN_NH_ESCAPE) << 1) | ((strand_plus) ? 1u : 0u))
+#define MM_ALN_TID(tsn) ((int32_t) ((tsn) >> (MM_ALN_NH_BITS + 1)) - 1)
+#define MM_ALN_STRAND(tsn) ((tsn) & 1u)
+#define MM_ALN_NH_FIELD(tsn) (((tsn) >> 1) & MM_ALN_NH_ESCAPE)
+/* side list of a batch: tuple `index` (its NH field holds MM_ALN_NH_ESCAPE) has nHits = nh; ascending by index */
+typedef struct mm_nh_big {
+  uint32_t index;
+  uint32_t nh;
+} mm_nh_big;
 
 typedef struct mm_index mm_index; /* IntervalList's index members, mmannot.cpp:1086-1090, resident in HBM */
 typedef struct mm_ctx mm_ctx;     /* one Counter (mmannot.cpp:1653-1664) on one GPU                      */
@@ -120,13 +134,21 @@ int mm_reset(mm_ctx *ctx);
 
 /* One batch of the per-alignment loop of Counter::read (mmannot.cpp:1772-1781): for every tuple,
  * scan() then addCount().  Asynchronous on the context's stream.
- *   on_device = 0: aln/nh are host buffers (pinned for overlap), copied with hipMemcpyAsync; they must
- *                  stay valid until mm_sync().
- *   on_device = 1: aln/nh are device pointers (inputs already resident in HBM).
+ *   aln: n tuples; host memory (copied with hipMemcpyAsync on a copy stream that overlaps the previous batch's kernels;
+ *        pinned memory - mm_host_alloc - for full PCIe rate; must stay valid until mm_sync() or until two further batches
+ *        have been submitted) or, with MM_BATCH_ON_DEVICE, device memory (inputs already resident in HBM).
+ *   big/n_big: host array, the NH values of the tuples whose NH field is MM_ALN_NH_ESCAPE, ascending by index; copied
+ *        before the call returns.
  *   qid_bound: exclusive upper bound of every qid seen so far including this batch (sizes the
- *              per-read-name state of -y default; ignored by the other strategies).
+ *        per-read-name state of -y default; ignored by the other strategies).
+ *   flags: MM_BATCH_ON_DEVICE; MM_BATCH_SINGLE_HIT = the caller promises that every tuple has NH <= 1 (checked on the
+ *        device, MM_ERR_ARG at the next mm_sync otherwise): the multi-hit pipeline is not launched at all.
  * Batches must be submitted in file order (the multi-hit countdown is order dependent, mmannot.cpp:1669-1701). */
-int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, const uint32_t *nh, size_t n, uint64_t qid_bound, int on_device);
+enum { MM_BATCH_ON_DEVICE = 1, MM_BATCH_SINGLE_HIT = 2 };
+int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_bound, uint32_t flags);
+/* pinned (page-locked) host memory for tuple batches: hipHostMalloc / hipHostFree */
+void *mm_host_alloc(size_t bytes);
+void mm_host_free(void *p);
 int mm_sync(mm_ctx *ctx);
 /* End of input: the flush of still-pending multi-hit reads, mmannot.cpp:1783-1792. Synchronises. */
 int mm_finalize(mm_ctx *ctx);
@@ -201,8 +223,10 @@ int mm_reader_open(mm_reader **out, const char *path, int format, const mm_annot
                    int unique_only /* -y unique: reads with NH != 1 never reach scan(), so they raise no chromosome warning */,
                    int keep_names /* keep qid -> name (needed by -m) */);
 const char *mm_reader_error(const mm_reader *r);
-/* Reader::gotoNextRead x cap: fills up to cap tuples; *n = 0 at end of file */
-int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t cap, size_t *n);
+/* Reader::gotoNextRead x cap: fills up to cap tuples; *n = 0 at end of file.  NH values that do not fit the tuple's NH field go
+ * to big[] (capacity big_cap >= 1; the batch ends early when it is full), *n_big of them.  *max_nh (may be NULL) receives the
+ * largest NH of the batch: <= 1 allows MM_BATCH_SINGLE_HIT. */
+int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n, mm_nh_big *big, size_t big_cap, size_t *n_big, uint32_t *max_nh);
 uint64_t mm_reader_qid_bound(const mm_reader *r);
 uint64_t mm_reader_n_reads(const mm_reader *r);       /* the "lines read" counter of Counter::read, mmannot.cpp:1782 */
 const char *mm_reader_name(const mm_reader *r, uint32_t qid);
@@ -215,14 +239,14 @@ typedef struct mm_synth_params {
   uint64_t seed;
   uint64_t first;          /* index of the first alignment of this batch in the stream        */
   int32_t read_len;        /* every read is <read_len>M                                        */
-  int32_t nh_max;          /* 1: every read NH=1; k>1: groups with NH = 1..k, exactly NH hits  */
+  int32_t nh_max;          /* 1: every read NH=1; k>1 (<= 2046): groups with NH = 1..k, exactly NH hits */
   int32_t n_chromosomes;
   const int64_t *chr_len;  /* host array [n_chromosomes]                                       */
   uint32_t scatter_log2;   /* hits of one read are spread over windows of 2^scatter_log2 tuples */
   uint32_t pair_insert;    /* > 0 (needs nh_max 1): tuples 2p, 2p+1 are mates - one name, opposite strands,
                             * starts pair_insert + 0..63 apart (BASELINE.json configs[3])          */
 } mm_synth_params;
-int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_params *p, void *stream);
+int mm_synth_fill(void *d_aln, size_t n, const mm_synth_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,12 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 extern "C" const char *mm_last_error(void) { return g_err.c_str(); }
 extern "C" const char *mm_version(void) { return MM_VERSION; }
+extern "C" void *mm_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { g_err = "mm_host_alloc: hipHostMalloc failed"; return nullptr; }
+  return p;
+}
+extern "C" void mm_host_free(void *p) { if (p) (void) hipHostFree(p); }
 extern "C" int mm_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -70,6 +76,7 @@ extern "C" int mm_device_count(void) {
 #define LT_CAP 512u                // per-workgroup LDS table (with 1024 entries the merge kernel could not hold 8 waves per SIMD)
 #define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
+#define GT_NO_SLOT (GT_CAP - 1u)   // payload value "empty set" of a multi-hit record; gt_find_or_insert never returns this slot
 #define MM_LDS_CHR 256               // chromosome tables up to this size are staged in LDS by k_probe
 // k_probe is a chain of dependent gathers (tuple -> slot line -> rest of the line), i.e. latency bound: it runs at the
 // hardware's maximum of 8 waves per SIMD (<= 64 VGPRs, < 20 KB LDS per 256 threads).  Measured on MI355X against the
@@ -117,8 +124,26 @@ struct GlobalTable {
   u64 *key;      // 0 = empty (an element set is never empty)
   u64 *cnt;      // integer count (default / unique)
   double *sum;   // -y ratio accumulator (file-order double adds, mmannot.cpp:1730)
-  u32 *err;      // set to 1 when the table is full
+  u32 *err;      // ERR_* of the first problem a kernel met (0 = none); read by mm_sync
 };
+enum { ERR_TABLE_FULL = 1, ERR_QID_BOUND = 2, ERR_SINGLE_HIT = 3, ERR_NH_LIST = 4 };
+
+// mm_aln.tsn = strand:1 | NH:11 | (chromosome + 1):20 (include/mmannot_amd.h)
+#define TSN_TID1(z) ((u32) (z) >> (MM_ALN_NH_BITS + 1))
+// record.nHits of tuple i: the tuple's NH field, or - for the rare value that does not fit - the batch's side list
+// (ascending by tuple index).  A tuple that escapes without an entry is the caller's error.
+__device__ __forceinline__ u32 tuple_nh(u32 tsn, size_t i, const uint2 *__restrict__ big, u32 nbig, u32 *err) {
+  const u32 f = (tsn >> 1) & MM_ALN_NH_ESCAPE;
+  if (f != MM_ALN_NH_ESCAPE) return f;
+  u32 lo = 0, hi = nbig;
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (big[mid].x < (u32) i) lo = mid + 1; else hi = mid;
+  }
+  if (lo < nbig && big[lo].x == (u32) i) return big[lo].y;
+  atomicCAS(err, 0u, (u32) ERR_NH_LIST);
+  return f;
+}
 
 struct ProbeParams {
   const int4 *iv;          // {start, end, type | F<<8, exclusive prefix max of end within the chromosome}
@@ -213,10 +238,12 @@ __device__ __forceinline__ u32 slot_of_set(LdsTable &t, const struct GlobalTable
   return lds_cached_slot(t, g, m);
 }
 
-// returns slot or NO_KEY when full (error flag raised)
+// returns slot or NO_KEY when full (error flag raised).  The last slot is never handed out: a multi-hit record's set travels
+// as a 16-bit slot number in its sort payload and GT_NO_SLOT there means "no element" (k_probe / k_chunk_default).
 __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
   u32 h = hash64(m) & (GT_CAP - 1);
   for (u32 p = 0; p < GT_CAP; ++p) {
+    if (h == GT_NO_SLOT) { h = 0; continue; }
     u64 k = *(volatile u64 *) &g.key[h];
     if (k == 0) {
       k = atomicCAS(&g.key[h], 0ull, m);
@@ -225,7 +252,7 @@ __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
     if (k == m) return h;
     h = (h + 1) & (GT_CAP - 1);
   }
-  atomicExch(g.err, 1u);
+  atomicCAS(g.err, 0u, (u32) ERR_TABLE_FULL);
   return NO_KEY;
 }
 
@@ -514,8 +541,8 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
 //     ordered -y ratio accumulation, or
 //   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
 template <int OVL>
-__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const u32 *__restrict__ nhp,
-                                               size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
+__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
+                                               int single, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
                                                u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
                                                u64 *__restrict__ walkstat) {
   __shared__ LdsTable T;
@@ -543,7 +570,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     u32 nh = 1;
     if (valid) {
       a = ld_stream(aln + i);
-      if (nhp) nh = ld_stream(nhp + i);
+      nh = tuple_nh((u32) a.z, i, big, nbig, G.err);
+      if (single && nh > 1) { atomicCAS(G.err, 0u, (u32) ERR_SINGLE_HIT); nh = 1; }   // MM_BATCH_SINGLE_HIT was a promise
     }
     const bool processed = valid && !(P.strategy == MM_STRAT_UNIQUE && nh != 1);  // mmannot.cpp:1773
     u64 mask = 0;
@@ -551,8 +579,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       const int rec_strand = a.z & 1;
       const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
       // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
-      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, (u32) a.z >> 1, rstrand, walked)
-                                        : probe_one<OVL>(P, a.x, a.y, (u32) a.z >> 1, rstrand, walked);
+      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
+                                        : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
     }
     const int np = __popcll(mask);
     const bool grouped = processed && grouped_strategy && nh > 1;
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     cMulti += __popcll(__ballot(grouped));
     cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
     const bool counted = processed && !grouped && mask != 0 && P.strategy != MM_STRAT_RANDOM;   // mmannot.cpp:1704 (random: the caller decides)
-    u32 key = NO_KEY, pay = 0xFFFFu;
+    u32 key = NO_KEY, pay = GT_NO_SLOT;
     if (grouped) {
       key = (u32) a.w;
       qinv = max(qinv, ~key); qmax = max(qmax, key);
@@ -576,7 +604,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     if (counted && !ratio) count_set(T, G, mask);
     if ((ratio && counted) || (grouped && mask != 0)) {
       const u32 slot = slot_of_set(T, G, mask);
-      if (ratio) key = slot; else pay = slot & 0xFFFFu;
+      if (ratio) key = slot; else pay = slot & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
     }
     if (valid) {
       if (gkey) {
@@ -946,14 +974,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
 // gathers in flight - measured 0.20 -> 0.16 ms per 2^24 records against its default schedule of 54 VGPRs)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chunk_default(const u32 *__restrict__ kA, const u32 *__restrict__ vA, const u32 *__restrict__ kB,
                                                        const u32 *__restrict__ vB, const u32 *__restrict__ info,
-                                                       const u32 *__restrict__ nhp, const u64 *__restrict__ hm, u32 *__restrict__ grpRem,
+                                                       const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig, const u64 *__restrict__ hm, u32 *__restrict__ grpRem,
                                                        u64 *__restrict__ grpU, u64 qcap, GlobalTable G, u64 *__restrict__ stats, int nelem) {
   __shared__ LdsTable T;
   __shared__ u32 sOpened, sRescued;
   __shared__ u32 sKey[256 + 64], sNh[256 + 64];   // this round's records and the 64 behind them
   __shared__ u64 sM[256 + 64];
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
-  if (info[INFO_M] != 0 && (u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicExch(G.err, 2u); return; }
+  if (info[INFO_M] != 0 && (u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
   lds_table_init(T);
   if (threadIdx.x == 0) { sOpened = 0; sRescued = 0; }
   __syncthreads();
@@ -967,8 +995,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   u32 opened = 0, rescued = 0;
   // payload of a record of the sorted stream -> (element set, NH)
   auto decode = [&](u32 pv, u64 &m, u32 &nhv) __attribute__((always_inline)) {
-    if (by_index) { m = hm[pv]; nhv = nhp[pv]; }
-    else { const u32 slot = pv & 0xFFFFu; m = (slot == 0xFFFFu) ? 0ull : G.key[slot]; nhv = pv >> 16; }
+    if (by_index) { m = hm[pv]; nhv = tuple_nh((u32) aln[pv].z, pv, big, nbig, G.err); }
+    else { const u32 slot = pv & 0xFFFFu; m = (slot == GT_NO_SLOT) ? 0ull : G.key[slot]; nhv = pv >> 16; }
   };
   auto fetch = [&](size_t k, u64 &m, u32 &nhv) __attribute__((always_inline)) { decode(svals[k], m, nhv); };
   auto close_group = [&](u64 U) __attribute__((always_inline)) {
@@ -1409,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_hit_intervals(const ProbeParams P, cons
       const int rec_strand = a.z & 1;
       const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
       Cand cd;
-      if (locate(P, (u32) a.z >> 1, s, cd)) {
+      if (locate(P, TSN_TID1(a.z), s, cd)) {
         u32 w = FILL ? off[i] : 0u;
         for (u32 k = cd.a0; k < cd.a1; ++k) {
           const int4 r = P.act[k];
@@ -1445,7 +1473,7 @@ __host__ __device__ inline u64 splitmix64(u64 x) {
   return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restrict__ aln, u32 *__restrict__ nhp, size_t n) {
+__global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restrict__ aln, size_t n) {
   for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t) gridDim.x * blockDim.x) {
     const u64 i = S.first + j;
     // physical index -> logical hit index: affine permutation inside windows of 2^scatter_log2
@@ -1479,10 +1507,9 @@ __global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restric
     int4 a;
     a.x = (int) (pos0 + 1);
     a.y = a.x + S.read_len - 1;
-    a.z = (int) ((((u32) c + 1u) << 1) | (u32) (((h >> 63) ^ mate) & 1ull));
+    a.z = (int) MM_ALN_PACK(c, ((h >> 63) ^ mate) & 1ull, nh);
     a.w = (int) (u32) qid;
     aln[j] = a;
-    if (nhp) nhp[j] = nh;
   }
 }
 
@@ -1518,10 +1545,14 @@ struct mm_ctx {
   // batch buffers
   size_t cap = 0;
   int4 *d_aln = nullptr;   // = d_alnBuf[cur]
-  u32 *d_nh = nullptr;
   // host-tuple path: two staging sets filled by a dedicated copy stream, so the copy of batch k+1 overlaps the kernels of batch k
   int4 *d_alnBuf[2] = {nullptr, nullptr};
-  u32 *d_nhBuf[2] = {nullptr, nullptr};
+  // NH values too large for the tuple's NH field: the caller's (index, NH) list, staged through pinned memory (two sets)
+  uint2 *d_big[2] = {nullptr, nullptr}, *h_big[2] = {nullptr, nullptr};
+  size_t big_cap[2] = {0, 0};
+  hipEvent_t ev_big[2] = {nullptr, nullptr};
+  bool big_valid[2] = {false, false};
+  int big_cur = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   bool consumed_valid[2] = {false, false};
@@ -1582,6 +1613,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   const int E = el->n_elements;
   if (E < 1 || E > MM_MAX_ELEMENTS) return fail(MM_ERR_RANGE, "mm_index_create: number of Order elements must be 1..64");
   if (n_chromosomes < 1) return fail(MM_ERR_ARG, "mm_index_create: no chromosome");
+  if (n_chromosomes > MM_ALN_MAX_CHROMOSOMES) return fail(MM_ERR_RANGE, "mm_index_create: more chromosomes than the tuple's 20-bit chromosome field holds");
   if (n_iv == 0) return fail(MM_ERR_ARG, "mm_index_create: empty interval list (the reference exits here, mmannot.cpp:1285-1288)");
   if (n_iv >= 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_index_create: too many intervals");
   int rc = device_check(device);
@@ -1794,12 +1826,12 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 }
 
 static void ctx_free_batch(mm_ctx *c) {
-  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); (void) hipFree(c->d_nhBuf[b]); c->d_alnBuf[b] = nullptr; c->d_nhBuf[b] = nullptr; c->consumed_valid[b] = false; }
+  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); c->d_alnBuf[b] = nullptr; c->consumed_valid[b] = false; }
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
   c->d_tileTot = nullptr; c->d_tileK = nullptr;
-  c->d_aln = nullptr; c->d_nh = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
+  c->d_aln = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
   c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr;
   c->cap = 0;
 }
@@ -1838,6 +1870,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
+  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_big[b]); (void) hipHostFree(c->h_big[b]); if (c->ev_big[b]) (void) hipEventDestroy(c->ev_big[b]); }
   if (c->copy_stream) {
     (void) hipStreamSynchronize(c->copy_stream);
     for (int b = 0; b < 2; ++b) { (void) hipEventDestroy(c->ev_copied[b]); (void) hipEventDestroy(c->ev_consumed[b]); }
@@ -1878,13 +1911,13 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     c->cap = cap;
   }
   if (need_copy && !c->d_alnBuf[0]) {
-    for (int b = 0; b < 2; ++b) { HIPCHK(hipMalloc((void **) &c->d_alnBuf[b], c->cap * sizeof(int4))); HIPCHK(hipMalloc((void **) &c->d_nhBuf[b], c->cap * 4)); }
+    for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc((void **) &c->d_alnBuf[b], c->cap * sizeof(int4)));
     if (!c->copy_stream) {
       HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
       for (int b = 0; b < 2; ++b) { HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_consumed[b], hipEventDisableTiming)); }
     }
   }
-  c->d_aln = c->d_alnBuf[0]; c->d_nh = c->d_nhBuf[0];
+  c->d_aln = c->d_alnBuf[0];
   return MM_OK;
 }
 
@@ -1974,19 +2007,47 @@ static void free_runs(mm_ctx *c) {
   c->runs.clear();
 }
 
-extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *nh, size_t n, uint64_t qid_bound, int on_device) {
+// the batch's (index, NH) side list -> device, through one of two pinned staging sets (the caller's array is free on return)
+static int stage_big(mm_ctx *c, const mm_nh_big *big, size_t n_big, size_t n, const uint2 **d_out) {
+  *d_out = nullptr;
+  if (n_big == 0) return MM_OK;
+  if (!big) return fail(MM_ERR_ARG, "mm_annotate_batch: n_big > 0 without a list");
+  for (size_t k = 0; k < n_big; ++k)
+    if (big[k].index >= n || (k && big[k].index <= big[k - 1].index)) return fail(MM_ERR_ARG, "mm_annotate_batch: the NH side list must be ascending by tuple index, indices below n");
+  const int b = c->big_cur; c->big_cur ^= 1;
+  if (c->big_valid[b]) HIPCHK(hipEventSynchronize(c->ev_big[b]));   // the copy that last used this set (two batches ago)
+  if (n_big > c->big_cap[b]) {
+    (void) hipFree(c->d_big[b]); (void) hipHostFree(c->h_big[b]); c->d_big[b] = nullptr; c->h_big[b] = nullptr;
+    const size_t cap = std::max<size_t>(2 * n_big, 1024);
+    HIPCHK(hipMalloc((void **) &c->d_big[b], cap * sizeof(uint2))); HIPCHK(hipHostMalloc((void **) &c->h_big[b], cap * sizeof(uint2), hipHostMallocDefault));
+    c->big_cap[b] = cap;
+  }
+  if (!c->ev_big[b]) HIPCHK(hipEventCreateWithFlags(&c->ev_big[b], hipEventDisableTiming));
+  memcpy(c->h_big[b], big, n_big * sizeof(uint2));
+  HIPCHK(hipMemcpyAsync(c->d_big[b], c->h_big[b], n_big * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->ev_big[b], c->stream)); c->big_valid[b] = true;
+  *d_out = c->d_big[b];
+  return MM_OK;
+}
+
+extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_bound, uint32_t flags) {
   if (!c) return fail(MM_ERR_ARG, "mm_annotate_batch: null context");
   if (c->finalized) return fail(MM_ERR_STATE, "mm_annotate_batch: context already finalized (call mm_reset)");
   if (n == 0) return MM_OK;
   if (!aln) return fail(MM_ERR_ARG, "mm_annotate_batch: null tuples");
   if (n > 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_annotate_batch: batch larger than 2^32 tuples");
+  if (flags & ~(uint32_t) (MM_BATCH_ON_DEVICE | MM_BATCH_SINGLE_HIT)) return fail(MM_ERR_ARG, "mm_annotate_batch: unknown flag");
+  const bool on_device = (flags & MM_BATCH_ON_DEVICE) != 0, single = (flags & MM_BATCH_SINGLE_HIT) != 0;
+  if (single && n_big) return fail(MM_ERR_ARG, "mm_annotate_batch: MM_BATCH_SINGLE_HIT with an NH side list");
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = ensure_batch(c, n, !on_device);
   if (rc) return rc;
   const bool dflt = c->opt.strategy == MM_STRAT_DEFAULT, ratio = c->opt.strategy == MM_STRAT_RATIO;
-  if (dflt && nh) { rc = ensure_qids(c, qid_bound ? qid_bound : 1); if (rc) return rc; }
+  if (dflt && !single) { rc = ensure_qids(c, qid_bound ? qid_bound : 1); if (rc) return rc; }
+  const uint2 *d_big = nullptr;
+  rc = stage_big(c, big, n_big, n, &d_big);
+  if (rc) return rc;
   const int4 *d_aln = (const int4 *) aln;
-  const u32 *d_nh = nh;
   int staged = -1;
   if (!on_device) {
     // copy stream: wait until the kernels that last read this staging set are done, copy, signal; the compute stream
@@ -1998,16 +2059,15 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
       t.stream_override = c->copy_stream;
       t.restart();
       HIPCHK(hipMemcpyAsync(c->d_alnBuf[b], aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->copy_stream));
-      if (nh) HIPCHK(hipMemcpyAsync(c->d_nhBuf[b], nh, n * 4, hipMemcpyHostToDevice, c->copy_stream));
     }
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
-    c->d_aln = c->d_alnBuf[b]; c->d_nh = c->d_nhBuf[b];
-    d_aln = c->d_aln; d_nh = nh ? c->d_nh : nullptr;
+    c->d_aln = c->d_alnBuf[b];
+    d_aln = c->d_aln;
   }
   ProbeParams P;
   fill_params(c, P);
-  const bool need_groups = (dflt && d_nh) || ratio;
+  const bool need_groups = (dflt && !single) || ratio;
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
   u64 *hm = c->d_hm;
   u32 *gkey = need_groups ? c->d_gkey : nullptr;
@@ -2016,13 +2076,13 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
   PhaseTimer t(c, MM_PHASE_PROBE);
   switch (c->opt.overlap_mode) {
     case MM_OVL_INCLUSION:
-      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     case MM_OVL_PC:
-      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     default:
-      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_nh, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
   }
   }
   HIPCHK(hipGetLastError());
@@ -2036,7 +2096,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, const uint32_t *n
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
     if (dflt)
-      hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_nh, hm,
+      hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_aln, d_big, (u32) n_big, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
     else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
       mm_ctx::Run r;
@@ -2060,8 +2120,10 @@ static int check_table(mm_ctx *c) {
   u32 err = 0;
   HIPCHK(hipMemcpyAsync(&err, c->G.err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (err == 2) return fail(MM_ERR_ARG, "a read-name id (qid) of the batch is not below the qid_bound given to mm_annotate_batch; the batch's multi-hit records were not merged");
-  if (err) return fail(MM_ERR_TABLE_FULL, "more than 65536 distinct element sets");
+  if (err == ERR_QID_BOUND) return fail(MM_ERR_ARG, "a read-name id (qid) of the batch is not below the qid_bound given to mm_annotate_batch; the batch's multi-hit records were not merged");
+  if (err == ERR_SINGLE_HIT) return fail(MM_ERR_ARG, "a batch submitted with MM_BATCH_SINGLE_HIT holds a tuple with NH > 1");
+  if (err == ERR_NH_LIST) return fail(MM_ERR_ARG, "a tuple's NH field is MM_ALN_NH_ESCAPE but the batch's NH side list has no entry for it");
+  if (err) return fail(MM_ERR_TABLE_FULL, "more than 65535 distinct element sets");
   return MM_OK;
 }
 
@@ -2223,10 +2285,10 @@ extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
   return MM_OK;
 }
 
-extern "C" int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_params *p, void *stream) {
+extern "C" int mm_synth_fill(void *d_aln, size_t n, const mm_synth_params *p, void *stream) {
   if (!d_aln || !p || !p->chr_len) return fail(MM_ERR_ARG, "mm_synth_fill: null argument");
   if (p->n_chromosomes < 1 || p->n_chromosomes > 64) return fail(MM_ERR_ARG, "mm_synth_fill: 1..64 chromosomes");
-  if (p->nh_max < 1 || p->nh_max > 4096 || p->read_len < 1) return fail(MM_ERR_ARG, "mm_synth_fill: bad nh_max/read_len");
+  if (p->nh_max < 1 || p->nh_max >= (int) MM_ALN_NH_ESCAPE || p->read_len < 1) return fail(MM_ERR_ARG, "mm_synth_fill: bad nh_max/read_len");
   SynthDev S;
   S.seed = p->seed; S.first = p->first; S.read_len = p->read_len; S.nh_max = p->nh_max; S.nchr = p->n_chromosomes;
   S.scatter_log2 = p->scatter_log2; S.pair_insert = p->pair_insert;
@@ -2238,7 +2300,7 @@ extern "C" int mm_synth_fill(void *d_aln, void *d_nh, size_t n, const mm_synth_p
   }
   if (n == 0) return MM_OK;
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, (hipStream_t) stream, S, (int4 *) d_aln, (u32 *) d_nh, n);
+  hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, (hipStream_t) stream, S, (int4 *) d_aln, n);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }

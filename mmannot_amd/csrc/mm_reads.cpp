@@ -6,6 +6,8 @@
 //   NH is honoured only when stored in an unsigned BAM type (C/S/I), signed types give 0; default 1;
 //   an XA tag replays its equal-NM alternatives as further reads and sets nHits = alternatives+1;
 //   the unmapped flag is ignored; tid -1 is the chromosome "*".
+// Output: 16-byte tuples with NH packed beside chromosome and strand (include/mmannot_amd.h: mm_aln), NH values beyond the
+// field in a side list.
 // Read strand: the reference's XamRecord::setFlags ignores its argument, which makes its -s F/R
 // undefined.  Default here = the intended meaning (flag 0x10 clear -> '+'); MM_STRAND_COMPAT_* reproduce what a
 // given verbatim run did (every record '+', or every record '-').
@@ -649,11 +651,17 @@ extern "C" int mm_reader_open(mm_reader **out, const char *path, int format, con
 extern "C" const char *mm_reader_error(const mm_reader *r) { return r ? r->err.c_str() : "null reader"; }
 
 // Reader::gotoNextRead: the record itself, then each of its XA alternatives, as separate reads
-extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t cap, size_t *n_out) {
-  if (!r || !aln || !nh || !n_out) return MM_ERR_ARG;
-  size_t n = 0;
+extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n_out, mm_nh_big *big, size_t big_cap, size_t *n_big, uint32_t *max_nh) {
+  if (!r || !aln || !n_out || !big || !n_big || big_cap < 64) return MM_ERR_ARG;
+  size_t n = 0, nb = 0;
+  uint32_t mx = 0;
+  *n_big = 0;
+  if (max_nh) *max_nh = 0;
   uint64_t &cur_end = r->cur_end;
-  while (n < cap && !r->over) {
+  // NH travels inside the tuple; the rare value beyond the field goes to the side list (the batch ends while that list
+  // still has room for a whole run of fast-path records)
+  auto put_nh = [&](size_t i, uint32_t v) { if (v > mx) mx = v; if (v >= MM_ALN_NH_ESCAPE) { big[nb].index = (uint32_t) i; big[nb].nh = v; ++nb; } };
+  while (n < cap && !r->over && nb + 33 <= big_cap) {
     // Runs of ordinary BAM records: parsed in place a few at a time, so that the read-name dictionary's cache misses
     // (requested while parsing) overlap instead of adding up; then finished one by one in file order.
     if (r->is_bam && r->allow_fast && !(r->have_record && r->alt_next < r->alts.size())) {
@@ -665,7 +673,7 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
           const FastRec &f = fr[k];
           if (f.start > 0x7FFFFFF0ull || (f.end > 0x7FFFFFF0ull && f.end != f.start - 1)) {
             r->err = std::string("alignment coordinate outside the supported range [0, 2^31) for read ") + std::string(f.name, f.name_len);
-            *n_out = n; return MM_ERR_RANGE;
+            *n_out = n; *n_big = nb; if (max_nh) *max_nh = mx; return MM_ERR_RANGE;
           }
           const bool strand = (r->strand_compat == MM_STRAND_COMPAT_PLUS) ? true : (r->strand_compat == MM_STRAND_COMPAT_MINUS ? false : f.strand);
           const bool reaches_scan = !r->unique_only || f.nhits == 1;   // mmannot.cpp:1773
@@ -673,9 +681,9 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
           if (tid == -2 || (tid < 0 && reaches_scan)) { tid = tid_of(r, r->bam_chr[f.ref], reaches_scan); r->bam_tid[f.ref] = tid; }
           aln[n].start = (int32_t) f.start;
           aln[n].end = (int32_t) (int64_t) f.end;
-          aln[n].tid_strand = MM_ALN_TID_STRAND(tid, strand);
+          aln[n].tsn = MM_ALN_PACK(tid, strand, f.nhits);
           aln[n].qid = r->qids.get(f.name, f.name_len, f.hash);
-          nh[n] = f.nhits;
+          put_nh(n, f.nhits);
           ++n; ++r->n_reads;
         }
         // state the general path and the end-of-file replay look at: the last record, which has nothing to complain about
@@ -699,7 +707,7 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
       if (!ok) {
         r->over = true;
         if (r->err.empty() && !r->src.err.empty()) r->err = r->src.err + " in '" + r->path + "'";
-        if (!r->err.empty()) { r->have_record = false; *n_out = n; return MM_ERR_PARSE; }
+        if (!r->err.empty()) { r->have_record = false; *n_out = n; *n_big = nb; if (max_nh) *max_nh = mx; return MM_ERR_PARSE; }
         // At end of file the reference calls read.reset() once more on the stale last record (mmannot.cpp:1414-1415,
         // 1444-1447, 1527-1532): its CIGAR is parsed again and any complaint about it is printed a second time.
         if (r->have_record) (void) cigar_end(r->cigar, r->rec_start, r->rec_start, r->log);
@@ -713,7 +721,7 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
     }
     cur_end = end;
     if (start > 0x7FFFFFF0ull || (end > 0x7FFFFFF0ull && end != start - 1)) {
-      r->err = std::string("alignment coordinate outside the supported range [0, 2^31) for read ") + r->name_buf; *n_out = n; return MM_ERR_RANGE;
+      r->err = std::string("alignment coordinate outside the supported range [0, 2^31) for read ") + r->name_buf; *n_out = n; *n_big = nb; if (max_nh) *max_nh = mx; return MM_ERR_RANGE;
     }
     const bool reaches_scan = !r->unique_only || r->nhits == 1;   // mmannot.cpp:1773
     int32_t tid;
@@ -724,12 +732,13 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, uint32_t *nh, size_t ca
     const uint32_t q = r->qids.get(r->name_buf, r->name_len);
     aln[n].start = (int32_t) start;
     aln[n].end = (int32_t) (int64_t) end;
-    aln[n].tid_strand = MM_ALN_TID_STRAND(tid, strand);
+    aln[n].tsn = MM_ALN_PACK(tid, strand, r->nhits);
     aln[n].qid = q;
-    nh[n] = r->nhits;
+    put_nh(n, r->nhits);
     ++n; ++r->n_reads;
   }
-  *n_out = n;
+  *n_out = n; *n_big = nb;
+  if (max_nh) *max_nh = mx;
   return MM_OK;
 }
 

@@ -298,3 +298,62 @@ def test_ratio_chain_across_contexts(gpu_lib, oracle):
     want = dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
     assert got == want
     a.close(); b.close(); index.close()
+
+
+def _home_slot(mask):
+    """hash64 of mm_device.hip: home slot of an element set in the 65,536-slot device table."""
+    return ((int(mask) * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) >> 40 & 0xFFFF
+
+
+def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
+    """A multi-hit record's element set travels to the merge kernel as its 16-bit table slot and 0xFFFF there means "no
+    element".  Sets whose home slot is 65535 ({0,10,13,16,17,18,20}, {20,39,49}) or that linear probing pushes there (two
+    sets with home 65534) must still reach their group's union (mmannot.cpp:1678-1690): one Order line of 21 tied elements,
+    -l -1, NH = 2 reads inside intervals of exactly those elements."""
+    import synth_ref  # noqa: F401  (path set-up)
+    from oracle import mm_oracle as mo
+    mm = gpu_lib
+    E = 21
+    desc = mo.ConfigDesc([mo.Element("s", f"t{e}", 0, 0) for e in range(E)])
+    target = sum(1 << e for e in (0, 10, 13, 16, 17, 18, 20))
+    assert target == 1516545 and _home_slot(target) == 65535
+    allm = np.arange(1, 1 << E, dtype=np.uint64)
+    home = ((allm * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) & np.uint64(0xFFFF)
+    at_last = [target] + [int(m) for m in allm[home == 65535] if bin(int(m)).count("1") >= 2 and int(m) != target][:2]
+    before_last = [int(m) for m in allm[home == 65534] if bin(int(m)).count("1") >= 2][:3]   # the 2nd and 3rd probe on to 65535
+    assert target in at_last and len(before_last) == 3
+    sets = at_last + before_last + [0b11, 1 << 5]
+    chr_, start, end, typ = [], [], [], []
+    for j, m in enumerate(sets):
+        base = 10000 * (j + 1)
+        for e in range(E):
+            if m >> e & 1:
+                chr_.append(0); start.append(base + 100); end.append(base + 900); typ.append(e)
+    order = np.lexsort((np.arange(len(start)), start))
+    ix = dict(chr=np.array(chr_, dtype=np.int32)[order], start=np.array(start, dtype=np.int64)[order], end=np.array(end, dtype=np.int64)[order],
+              type=np.array(typ, dtype=np.int32)[order], strand=np.ones(len(start), dtype=np.uint8), n_chromosomes=1)
+    # reads: name q has NH = 2; its two hits sit in regions a(q), b(q) (often the same region, sometimes one in empty space)
+    rng = np.random.default_rng(65535)
+    tid, st, en, nh, qid = [], [], [], [], []
+    for q in range(600):
+        a = int(rng.integers(0, len(sets)))
+        b = a if rng.random() < 0.5 else int(rng.integers(0, len(sets) + 1))
+        for r in (a, b):
+            base = 10000 * (r + 1) if r < len(sets) else 5000        # 5000: no interval there
+            s = base + 200 + int(rng.integers(0, 50))
+            tid.append(0); st.append(s); en.append(s + 49); nh.append(2); qid.append(q)
+    perm = rng.permutation(len(st))
+    reads = dict(tid=np.array(tid, dtype=np.int32)[perm], start=np.array(st, dtype=np.int64)[perm], end=np.array(en, dtype=np.int64)[perm],
+                 strand=np.ones(len(st), dtype=np.uint8), nh=np.array(nh, dtype=np.uint32)[perm], qid=np.array(qid, dtype=np.int64)[perm])
+    cfg = to_cfg(mm, desc)
+    for order_kind in ("shuffled", "grouped"):
+        if order_kind == "grouped":
+            o = np.argsort(reads["qid"], kind="stable")
+            reads = {k: v[o] for k, v in reads.items()}
+        ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="U", strategy="default", want_hit_mask=True)
+        assert target in set(ref.hit_mask.tolist()) and target in set(ref.row_mask.tolist())
+        for batches in (1, 3):
+            r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="U", strategy="default", batches=batches)
+            assert (r["hit"] == ref.hit_mask).all()
+            assert r["stats"] == ref.stats, (order_kind, batches)
+            assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order_kind, batches)
