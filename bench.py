@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — annotated alignments / second of the overlap-and-count hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--batch-log2 B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--batch-log2 B] [--scaling weak|strong]
 
 One process per GPU (the driver launches N>1 through torch.distributed.run; backend "nccl" = RCCL).
-A step = one batch of 2^B synthetic alignment tuples, generated on the device beforehand (inputs are
-resident in HBM when the timed region starts), pushed through mm_annotate_batch: probe -> strand / -l
-filter -> priority selection -> multi-hit merge -> per-set counts.  The timed region is K steps plus the
-end-of-file flush and the cross-rank table merge.  Prints ONE JSON line on rank 0.
+A step = one batch of 2^B synthetic 16-byte alignment tuples pushed through mm_annotate_batch: probe -> strand / -l filter ->
+priority selection -> multi-hit merge -> per-set counts.  Two legs run in the same invocation, on the same batches:
+
+  leg "from host" -> `value` (the metric of record, SURVEY.md 8d / BASELINE.md 4.3): the tuple batches start in PINNED HOST memory;
+      the timed region holds the hipMemcpyAsync of every batch (the library's copy stream, overlapped with the kernels of the
+      previous batch), all kernels, the end-of-file flush and the cross-rank table merge.  `h2d` reports the link rate.
+  leg "resident"  -> `kernel_only`: the same batches already resident in HBM (no copy in the timed region); this is the leg
+      the `roofline` block of the dominant kernel is measured on, with HIP events around its launches.
+
+Prints ONE JSON line on rank 0.
 
 Workloads (BASELINE.json configs):
   c3 (default): 100 bp single-end reads, read groups with NH = 1..20 (exactly NH hits each, scattered over
@@ -18,6 +24,8 @@ Workloads (BASELINE.json configs):
       vicinity (-d/-D 1000), -l 50, under -s U: the reference's parser rejects -s FR, so -s U is
       the only setting of this configuration that has an oracle.
   c5: NH = 1..100 groups, -y ratio, HS38-scale annotation.
+--scaling weak (default): every rank runs K batches of 2^B tuples; strong: the K x 2^B tuples of the job are split over the
+ranks (every rank runs K batches of 2^B / N tuples).
 """
 from __future__ import annotations
 
@@ -33,7 +41,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG_PROBE = 32.0  # algorithmic bytes / alignment of the probe kernel: 16 B tuple + 16 B index
+B_ALG_PROBE = 32.0   # algorithmic bytes / alignment of the probe kernel: 16 B tuple + 16 B index
+B_ALG_H2D = 16.0     # bytes / alignment that have to cross the link (SURVEY.md 8d "stream in")
+PCIE_PEAK_GBS = 63.0  # PCIe Gen5 x16, one direction: 32 GT/s x 16 lanes x 128/130
 
 # BASELINE.json configs -> (annotation shape, scale, read length, NH max, scatter window log2, mate distance, strategy, -l, -s)
 WORKLOADS = {
@@ -59,8 +69,9 @@ def main():
     ap.add_argument("--bin-shift", type=int, default=0, help="log2 of the index bin width (0 = the library's choice)")
     ap.add_argument("--scatter-log2", type=int, default=-1, help="informational: window over which a read's hits are spread (0 = hits adjacent, "
                     "an aligner's own output order; default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--legs", default="both", choices=("both", "host", "resident"), help="profiling aid: run only one leg (the JSON line of record needs both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--from-host", action="store_true", help="informational: tuples start in pinned host memory (PCIe-inclusive rate, never `value` of record)")
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
     args = ap.parse_args()
 
@@ -93,7 +104,8 @@ def main():
     if args.scatter_log2 >= 0:
         wl["scatter"] = args.scatter_log2
         wl["name"] += f" [hits of a read spread over 2^{args.scatter_log2} tuples]"
-    an = synth.synth_annotation(wl["shape"], seed=args.seed, scale=wl["scale"], keep_genes=(rank == 0 and world == 1 and wl["strategy"] == "default"))
+    want_cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
+    an = synth.synth_annotation(wl["shape"], seed=args.seed, scale=wl["scale"], keep_genes=want_cpu)
     read_len, nh_max, scatter, pair, strategy, wname = wl["read_len"], wl["nh_max"], wl["scatter"], wl["pair"], wl["strategy"], wl["name"]
     cfg = mm.Config.from_json(an.config)
     index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank, bin_shift=args.bin_shift)
@@ -102,119 +114,145 @@ def main():
     ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy, stream=stream,
                      defer_ratio=(strategy == "ratio" and world > 1))
 
-    # ---------------- inputs: W+K batches per rank, resident in HBM (rank-local stream, rank-local read-name ids)
+    # ---------------- inputs: W+K batches per rank (rank-local stream, rank-local read-name ids)
     B = 1 << args.batch_log2
+    if args.scaling == "strong":
+        B = max(1 << 16, B // world)     # the job's K x 2^B tuples split over the ranks
     nb = args.warmup + args.steps
     chr_len = np.ascontiguousarray(an.chr_len, dtype=np.int64)
-    alns, nhs = [], []
+    single = nh_max == 1
+    alns = []
     for s in range(nb):
         a = torch.empty((B, 4), dtype=torch.int32, device=dev)
-        h = torch.empty(B, dtype=torch.int32, device=dev) if nh_max > 1 else None
         p = _lib.SynthParams(args.seed * 1000003 + rank, s * B, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
-        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), h.data_ptr() if h is not None else None, B, C.byref(p), stream))
-        alns.append(a); nhs.append(h)
+        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), B, C.byref(p), stream))
+        alns.append(a)
     torch.cuda.synchronize()
     groups_per_tuple = (nh_max / (nh_max * (nh_max + 1) / 2.0)) if nh_max > 1 else 1.0
+    qb = int(nb * B * groups_per_tuple) + nh_max + 2   # exclusive bound of the read-name ids of the whole stream (a larger bound is allowed)
+    total_tuples = world * nb * B
 
-    def qid_bound(step):  # exclusive bound of the read-name ids of the whole stream (known up front here; a larger bound is allowed)
-        return int(nb * B * groups_per_tuple) + nh_max + 2
+    def run_leg(from_host: bool):
+        """W warm-up steps, then K timed steps + end-of-file flush + cross-rank merge, bracketed by barrier + synchronize.
+        Returns (elapsed seconds = max over ranks, phases of the timed region, masks, sums, stats)."""
+        host = None
+        if from_host:   # pinned host copies of the same batches: the library's copy stream moves them (hipMemcpyAsync)
+            host = [a.cpu().pin_memory() for a in alns]
+        ctr.clear()
+        ctr.set_profiling(0)
 
-    host = None
-    if args.from_host:   # pinned host copies of the same batches; mm_annotate_batch then does the hipMemcpyAsync itself
-        host = [(a.cpu().pin_memory(), h.cpu().pin_memory() if h is not None else None) for a, h in zip(alns, nhs)]
+        def step(s):
+            if host is not None:
+                ctr.add_batch_host(host[s].data_ptr(), B, qb, single_hit=single)
+            else:
+                ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
 
-    def run_step(s):
-        if host is not None:
-            ha, hh = host[s]
-            _lib.check(_lib.lib().mm_annotate_batch(ctr._h, C.c_void_p(ha.data_ptr()), C.c_void_p(hh.data_ptr()) if hh is not None else None, B, qid_bound(s), 0))
-            return
-        ctr.add_batch_device(alns[s].data_ptr(), nhs[s].data_ptr() if nhs[s] is not None else None, B, qid_bound(s))
-
-    for s in range(args.warmup):
-        run_step(s)
-    ctr.sync()
-    # Timed region: HIP events around the probe launches only (the roofline's live measurement); every recorded event costs a few
-    # microseconds of stream time, so the other phases are timed in a separate, untimed pass afterwards.
-    ctr.set_profiling(2)
-    if world > 1:
-        # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
-        if strategy == "ratio":
-            warm_up(device=comm_dev, p2p=True)
+        for s in range(args.warmup):
+            step(s)
+        ctr.sync()
+        # HIP events around the probe launches and the copies only: every recorded event costs a few microseconds of stream time
+        ctr.set_profiling(2)
+        if world > 1:
+            # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
+            if strategy == "ratio":
+                warm_up(device=comm_dev, p2p=True)
+            else:
+                merge_counts(*ctr.getCounts(), ctr.stats(), device=comm_dev)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.warmup, nb):
+            step(s)
+        ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
+        stats = ctr.stats()
+        if strategy == "ratio" and world > 1:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
+            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev)
         else:
-            merge_counts(*ctr.getCounts(), ctr.stats(), device=comm_dev)
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, nb):
-        run_step(s)
-    ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
-    stats = ctr.stats()
-    if strategy == "ratio" and world > 1:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
-        masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev)
-    else:
-        masks, sums = ctr.getCounts()
-        masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    phases = ctr.phase_ms()
-    # phase breakdown: the same batches once more on a cleared context, every phase bracketed by events (not part of `value`)
+            masks, sums = ctr.getCounts()
+            masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm_dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        phases = ctr.phase_ms()
+        ctr.set_profiling(0)
+        # size-independent sanity of the whole job (every tuple was handed to scan(); every group counted at most once)
+        assert stats["nHits"] == total_tuples, (stats, total_tuples)
+        assert strategy == "ratio" or int(np.rint(sums).sum()) <= stats["nReads"]
+        del host
+        return float(el.item()), phases, masks, sums, stats
+
+    res_host = run_leg(True) if args.legs in ("both", "host") else None
+    res_dev = run_leg(False) if args.legs in ("both", "resident") else None
+    if res_host is not None and res_dev is not None:   # the two legs are the same job
+        oh, od = np.argsort(res_host[2]), np.argsort(res_dev[2])
+        assert res_host[4] == res_dev[4] and np.array_equal(res_host[2][oh], res_dev[2][od])
+        assert np.array_equal(np.ascontiguousarray(res_host[3][oh]).view(np.uint64), np.ascontiguousarray(res_dev[3][od]).view(np.uint64))
+
+    # phase breakdown: resident batches once more on a cleared context, every phase bracketed by events (not part of any rate)
     n_phase = min(args.steps, 10)
-    ctr.set_profiling(0)
     if strategy == "ratio" and world > 1:      # (deferred accumulation: its merge phase runs inside the rank-to-rank chain)
-        phases_all = phases
+        phases_all = (res_dev or res_host)[1]
         n_phase = args.steps
     else:
         ctr.clear()
         for s in range(args.warmup):
-            run_step(s)
+            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
         ctr.sync()
         ctr.set_profiling(1)
         for s in range(args.warmup, args.warmup + n_phase):
-            run_step(s)
+            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
         ctr.sync()
         phases_all = ctr.phase_ms()
         ctr.set_profiling(0)
 
-    # size-independent sanity of the whole job (every tuple was handed to scan(); every group counted at most once)
-    total_tuples = world * nb * B
-    assert stats["nHits"] == total_tuples, (stats, total_tuples)
-    assert strategy == "ratio" or int(np.rint(sums).sum()) <= stats["nReads"]
-
     if rank == 0:
-        value = world * args.steps * B / elapsed
-        dom = max(("probe", "sort", "merge", "compact"), key=lambda p: phases_all[p][0])
-        probe_ms, probe_n = phases["probe"]
-        avg_probe_s = probe_ms / max(1, probe_n) / 1e3
-        achieved = B_ALG_PROBE * B / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get(args.workload, {}).get("k_probe_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        lead = res_host if res_host is not None else res_dev
+        elapsed, _, masks, sums, stats = lead
+        job = world * args.steps * B
         out = {
-            "metric": "annotated alignments/sec", "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "annotated alignments/sec", "value": job / elapsed, "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32/u64 (f64 only under -y ratio)", "data": "synthetic",
             "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "order_elements": len(an.config),
-                       "index_bytes": info, "sharding": "by read name, table merged by all_gather+all_reduce"},
-            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
-                         "dominant_phase": dom},
-            "phase_ms_per_step": {p: phases_all[p][0] / max(1, n_phase) for p in phases_all},
-            "phase_pass": f"separate untimed pass of {n_phase} steps with events around every phase",
+                       "index_bytes": info, "sharding": "by read name, table merged by all_gather+all_reduce",
+                       "input": "16-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region" if res_host is not None
+                                else "tuples resident in HBM (--legs resident: NOT the metric of record)"},
             "stats": stats, "table_rows": int(len(masks)),
         }
-        if args.from_host:
-            out["metric"] = "annotated alignments/sec INCLUDING the PCIe copy of pinned host tuples (informational)"
-        if not args.no_cpu_baseline and world == 1 and strategy == "default":
+        if res_host is not None:
+            h_ms, h_n = res_host[1]["h2d"]
+            avg_copy_s = h_ms / max(1, h_n) / 1e3
+            link = B_ALG_H2D * B / avg_copy_s / 1e9 if avg_copy_s > 0 else 0.0
+            out["h2d"] = {"bound": "pcie", "achieved": link, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": link / PCIE_PEAK_GBS,
+                          "alg_bytes_per_alignment": B_ALG_H2D, "avg_copy_ms": avg_copy_s * 1e3,
+                          "end_to_end": out["value"] / world * B_ALG_H2D / 1e9,
+                          "note": "achieved = 16 B x batch / average hipMemcpyAsync duration (HIP events on the copy stream, timed region); "
+                                  "end_to_end = per-GPU value x 16 B: what the whole pipeline sustains on the link"}
+        if res_dev is not None:
+            k_el, k_ph = res_dev[0], res_dev[1]
+            dom = max(("probe", "sort", "merge", "compact"), key=lambda p: phases_all[p][0])
+            probe_ms, probe_n = k_ph["probe"]
+            avg_probe_s = probe_ms / max(1, probe_n) / 1e3
+            achieved = B_ALG_PROBE * B / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
+            traffic = None
+            pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pj):
+                try:
+                    traffic = json.load(open(pj)).get(args.workload, {}).get("k_probe_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["kernel_only"] = {"value": job / k_el, "unit": "alignments/s", "ms_per_step": k_el / args.steps * 1e3,
+                                  "note": "same batches resident in HBM when the timed region starts (no copy); the roofline leg"}
+            out["roofline"] = {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
+                               "dominant_phase": dom}
+        out["phase_ms_per_step"] = {p: phases_all[p][0] / max(1, n_phase) for p in phases_all}
+        out["phase_pass"] = f"separate untimed pass of {n_phase} resident steps with events around every phase"
+        if want_cpu:
             port = cpu_baseline(args, an, wl, chr_len)
             ref = cpu_baseline_reference(args, an, wl, chr_len, index, cfg)
             if ref is not None:
@@ -237,20 +275,34 @@ def cpu_baseline(args, an, wl, chr_len):
     t = sr.synth_tuples(args.seed * 1000003, 0, n, wl["read_len"], wl["nh_max"], chr_len, wl["scatter"], wl["pair"])
     desc = mo.ConfigDesc.from_json(an.config)
     t0 = time.perf_counter()
-    r = mo.run(desc, an.as_index_dict(), t, overlap=wl["overlap"], strandedness=wl["strand"], strategy="default")
+    r = mo.run(desc, an.as_index_dict(), t, overlap=wl["overlap"], strandedness=wl["strand"], strategy=wl["strategy"])
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
             "sample": f"first 2^{args.cpu_sample_log2} alignments of rank 0's stream, oracle/mm_oracle.c single thread, {dt:.1f} s",
             "stats": r.stats}
 
 
+def _write_shard(job):
+    """(worker process) one BAM shard of rank 0's stream"""
+    (path, seed, first, n, read_len, nh_max, chr_len, scatter, pair, chroms) = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_ref as sr
+    from oracle import mm_oracle as mo
+    t = sr.synth_tuples(seed, first, n, read_len, nh_max, chr_len, scatter, pair)
+    body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"],
+                                np.full(n, read_len), t["nh"] if nh_max > 1 else None)
+    mo.write_bam_bytes(path, chroms, body, level=1)
+    return path
+
+
 def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     """The reference itself (oracle/_ref/mmannot_patched = v1.1 + the one-line strand fix that makes -s F deterministic,
     SURVEY.md F1), compiled in the build container, on a bounded sample of the same workload: the synthetic GTF and
-    configuration as files, S BAM shards of 2^21 alignments of rank 0's stream, one single-thread process per shard, all
-    running together (the reference parallelises over input files only, and its `-t` is not thread safe).  The GTF-loading
-    time (the same S processes on a one-read BAM) is subtracted.  Shard 0's count table must equal what the GPU path gives
-    for the same tuples."""
+    configuration as files, S BAM shards of rank 0's stream, S = every host core this process may use, one single-thread
+    process per shard, all running together (the reference parallelises over input files only, and its `-t` is not thread
+    safe).  The GTF-loading time (the same S processes on a one-read BAM) is subtracted.  Shard 0's count table must equal
+    what the GPU path gives for the same tuples."""
+    import multiprocessing
     import subprocess
     import tempfile
     ref = os.path.join(ROOT, "oracle", "_ref", "mmannot_patched")
@@ -261,22 +313,22 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     import mmannot_amd as mm
     from mmannot_amd import synth
     from oracle import mm_oracle as mo
-    read_len, nh_max, scatter = wl["read_len"], wl["nh_max"], wl["scatter"]
-    flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else [])
-    S = max(1, min(16, os.cpu_count() or 1))
-    n = 1 << 21
+    read_len, nh_max, scatter, strategy = wl["read_len"], wl["nh_max"], wl["scatter"], wl["strategy"]
+    flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else []) + (["-y", strategy] if strategy != "default" else [])
+    try:
+        S = len(os.sched_getaffinity(0))
+    except AttributeError:
+        S = os.cpu_count() or 1
+    S = max(1, S)
+    n = 1 << (21 if S <= 32 else 20)     # bounded sample: S shards, about 1-2 s of reference time each
     d = tempfile.mkdtemp(prefix="mmbench")
     gtf = os.path.join(d, "a.gtf"); open(gtf, "w").write(synth.gtf_text(an))
     cfgp = os.path.join(d, "c.cfg"); open(cfgp, "w").write(synth.config_text(an.shape))
     chroms = [(c, int(l)) for c, l in zip(an.chr_names, an.chr_len)]
-    shards, first_tuples = [], None
-    for i in range(S):
-        t = sr.synth_tuples(args.seed * 1000003, i * n, n, read_len, nh_max, chr_len, scatter, wl["pair"])
-        if i == 0:
-            first_tuples = t
-        body = mo.bam_records_fixed(t["tid"], t["start"] - 1, np.where(t["strand"] == 1, 0, 16).astype(np.uint16), t["qid"],
-                                    np.full(n, read_len), t["nh"] if nh_max > 1 else None)
-        p = os.path.join(d, f"s{i}.bam"); mo.write_bam_bytes(p, chroms, body, level=1); shards.append(p)
+    jobs = [(os.path.join(d, f"s{i}.bam"), args.seed * 1000003, i * n, n, read_len, nh_max, chr_len, scatter, wl["pair"], chroms) for i in range(S)]
+    with multiprocessing.get_context("fork").Pool(min(S, 32)) as pool:   # (fork: the workers only touch numpy and zlib)
+        shards = pool.map(_write_shard, jobs)
+    first_tuples = sr.synth_tuples(args.seed * 1000003, 0, n, read_len, nh_max, chr_len, scatter, wl["pair"])
     one = os.path.join(d, "one.bam")
     mo.write_bam_bytes(one, chroms, mo.bam_records_fixed(np.array([0]), np.array([100]), np.array([0], dtype=np.uint16), np.array([0]), np.array([read_len]), None), level=1)
 
@@ -309,12 +361,12 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
         shutil.rmtree(d, ignore_errors=True)
         return None
     # bench-time parity: GPU path on shard 0's tuples == the reference's table for shard 0
-    ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy="default")
+    ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy)
     t = first_tuples
     # the reference resolves chromosomes by name: reads on a chromosome without intervals are 'unknown' to it
     has_iv = np.zeros(an.n_chromosomes + 1, dtype=bool); has_iv[np.unique(an.chr)] = True
     tid = np.where(has_iv[t["tid"]], t["tid"], -1)
-    ctr.add_batch(mm.pack_alignments(tid, t["start"], t["end"], t["strand"], t["qid"]), t["nh"], int(t["qid"].max()) + 1)
+    ctr.add_batch(mm.pack_alignments(tid, t["start"], t["end"], t["strand"], t["qid"], t["nh"]), None, int(t["qid"].max()) + 1)
     ctr.flush()
     tab = mm.TableCount(cfg, 1); tab.addCounter(ctr)
     parity = tab.dump(["s0"]) == open(os.path.join(d, "t0.tsv")).read()
@@ -324,9 +376,9 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     import shutil
     shutil.rmtree(d, ignore_errors=True)
     return {"value": rate, "unit": "alignments/s", "cores": S, "kind": "reference",
-            "sample": f"{S} BAM shards x 2^21 alignments of rank 0's stream, {S} concurrent single-thread processes of oracle/_ref/mmannot_patched "
-                      f"(its own -t races): {t_full:.1f} s, {t_fixed:.1f} s of it GTF/config loading (measured the same way, subtracted); "
-                      f"one shard alone: {n / max(1e-9, t_one - t_fixed1):.3g} alignments/s",
+            "sample": f"{S} BAM shards x 2^{n.bit_length() - 1} alignments of rank 0's stream, {S} concurrent single-thread processes of "
+                      f"oracle/_ref/mmannot_patched (its own -t races) = every host core this process may use: {t_full:.1f} s, {t_fixed:.1f} s of it "
+                      f"GTF/config loading (measured the same way, subtracted); one shard alone: {n / max(1e-9, t_one - t_fixed1):.3g} alignments/s",
             "parity_table_vs_reference": bool(parity)}
 
 

@@ -179,8 +179,8 @@ int mm_set_row_sums(mm_ctx *ctx, const uint64_t *masks, const double *sums, size
 int mm_ratio_resolve(mm_ctx *ctx);
 
 /* Live timing with HIP events recorded on the context's stream around each phase of
- * mm_annotate_batch / mm_finalize (bench.py's roofline leg).  on = 0 off (default), 1 every phase, 2 the probe phase only
- * (every recorded event costs a few microseconds of stream time). */
+ * mm_annotate_batch / mm_finalize (bench.py's roofline leg).  on = 0 off (default), 1 every phase, 2 the probe phase and the
+ * host-to-device copies only (every recorded event costs a few microseconds of stream time; the copies have a stream of their own). */
 enum { MM_PHASE_H2D = 0, MM_PHASE_PROBE, MM_PHASE_COMPACT, MM_PHASE_SORT, MM_PHASE_MERGE, MM_PHASE_FLUSH, MM_N_PHASES };
 int mm_set_profiling(mm_ctx *ctx, int on);
 /* synchronises; ms[p] = summed duration of phase p since mm_set_profiling(ctx,1), launches[p] = how many spans */

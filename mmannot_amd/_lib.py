@@ -20,6 +20,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libmmannot_amd.so")
 
 MM_N_STATS = 7
+MM_BATCH_ON_DEVICE, MM_BATCH_SINGLE_HIT = 1, 2
+MM_ALN_NH_BITS = 11
+MM_ALN_NH_ESCAPE = (1 << MM_ALN_NH_BITS) - 1
 STAT_NAMES = ("nHits", "nReads", "nUnique", "nAmbiguous", "nMultiple", "nUnassigned", "nRescued")
 
 
@@ -58,7 +61,9 @@ SYMBOLS = {
     "mm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Options), C.c_void_p]),
     "mm_ctx_destroy": (None, [C.c_void_p]),
     "mm_reset": (C.c_int, [C.c_void_p]),
-    "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int]),
+    "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32]),
+    "mm_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "mm_host_free": (None, [C.c_void_p]),
     "mm_sync": (C.c_int, [C.c_void_p]),
     "mm_finalize": (C.c_int, [C.c_void_p]),
     "mm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -88,13 +93,14 @@ SYMBOLS = {
     "mm_index_from_annotation": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "mm_reader_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mm_reader_error": (C.c_char_p, [C.c_void_p]),
-    "mm_reader_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mm_reader_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                 C.POINTER(C.c_uint32)]),
     "mm_reader_qid_bound": (C.c_uint64, [C.c_void_p]),
     "mm_reader_n_reads": (C.c_uint64, [C.c_void_p]),
     "mm_reader_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mm_reader_take_log": (C.c_char_p, [C.c_void_p]),
     "mm_reader_close": (None, [C.c_void_p]),
-    "mm_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(SynthParams), C.c_void_p]),
+    "mm_synth_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(SynthParams), C.c_void_p]),
 }
 
 

@@ -27,18 +27,50 @@ OVL_INCLUSION, OVL_PC, OVL_NT = 0, 1, 2
 STRANDEDNESS = {"U": 0, "F": 1, "R": 2}
 STRATEGY = {"default": 0, "unique": 1, "random": 2, "ratio": 3}
 
-ALN_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("tid_strand", "<u4"), ("qid", "<u4")])
+ALN_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("tsn", "<u4"), ("qid", "<u4")])     # mm_aln, 16 bytes
+NH_BIG_DTYPE = np.dtype([("index", "<u4"), ("nh", "<u4")])                                     # mm_nh_big
+NH_BITS, NH_ESCAPE = _lib.MM_ALN_NH_BITS, _lib.MM_ALN_NH_ESCAPE
 
 
-def pack_alignments(tid, start, end, strand, qid) -> np.ndarray:
-    """SoA -> the 16-byte mm_aln tuples (include/mmannot_amd.h). tid < 0 = chromosome unknown to the annotation."""
+def pack_alignments(tid, start, end, strand, qid, nh=None) -> np.ndarray:
+    """SoA -> the 16-byte mm_aln tuples (include/mmannot_amd.h): tsn = strand | NH << 1 | (tid + 1) << 12.
+    tid < 0 = chromosome unknown to the annotation; nh None = every NH is 1; an NH beyond the 11-bit field becomes the escape
+    value (its true value then travels in the side list nh_side_list builds)."""
     n = len(start)
     a = np.empty(n, dtype=ALN_DTYPE)
     a["start"] = start
     a["end"] = end
-    a["tid_strand"] = ((np.asarray(tid, dtype=np.int64) + 1).astype(np.uint32) << np.uint32(1)) | (np.asarray(strand, dtype=np.uint32) & np.uint32(1))
+    nhf = np.ones(n, dtype=np.uint32) if nh is None else np.minimum(np.asarray(nh, dtype=np.uint64), NH_ESCAPE).astype(np.uint32)
+    a["tsn"] = ((np.asarray(tid, dtype=np.int64) + 1).astype(np.uint32) << np.uint32(NH_BITS + 1)) | (nhf << np.uint32(1)) | \
+        (np.asarray(strand, dtype=np.uint32) & np.uint32(1))
     a["qid"] = np.asarray(qid, dtype=np.uint32)
     return a
+
+
+def nh_side_list(nh) -> np.ndarray:
+    """mm_nh_big entries (ascending tuple index) for the NH values that do not fit the tuple's NH field."""
+    nh = np.asarray(nh, dtype=np.uint64)
+    idx = np.nonzero(nh >= NH_ESCAPE)[0]
+    big = np.empty(len(idx), dtype=NH_BIG_DTYPE)
+    big["index"] = idx
+    big["nh"] = nh[idx]
+    return big
+
+
+def aln_tid(aln) -> np.ndarray:
+    return (aln["tsn"] >> np.uint32(NH_BITS + 1)).astype(np.int64) - 1
+
+
+def aln_strand(aln) -> np.ndarray:
+    return (aln["tsn"] & np.uint32(1)).astype(np.uint8)
+
+
+def aln_nh(aln, big=None) -> np.ndarray:
+    """record.nHits of every tuple (NH field, side list applied)."""
+    nh = ((aln["tsn"] >> np.uint32(1)) & np.uint32(NH_ESCAPE)).astype(np.uint32)
+    if big is not None and len(big):
+        nh[big["index"]] = big["nh"]
+    return nh
 
 
 def overlap_mode_of(l: float) -> int:
@@ -157,20 +189,33 @@ class Counter:
     def clear(self):  # Counter::clear mmannot.cpp:1742-1747
         check(lib().mm_reset(self._h))
 
-    def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int):
-        """Host tuples (mm_aln structured array) -> one batch of the loop of Counter::read (mmannot.cpp:1772-1781)."""
+    def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int, single_hit: Optional[bool] = None):
+        """Host tuples (mm_aln structured array) -> one batch of the loop of Counter::read (mmannot.cpp:1772-1781).
+        nh given: the NH of every tuple (packed into a copy of the tuples, values beyond the field into the side list);
+        nh None: the tuples' own NH fields count."""
         aln = np.ascontiguousarray(aln)
         assert aln.dtype == ALN_DTYPE
-        nhp = None
+        big = np.empty(0, dtype=NH_BIG_DTYPE)
         if nh is not None:
-            nh = np.ascontiguousarray(nh, dtype=np.uint32)
-            nhp = nh.ctypes.data
-        self._keep.append((aln, nh))
-        check(lib().mm_annotate_batch(self._h, aln.ctypes.data, nhp, len(aln), int(qid_bound), 0))
+            nh = np.asarray(nh, dtype=np.uint64)
+            aln = aln.copy()
+            aln["tsn"] = (aln["tsn"] & ~np.uint32(NH_ESCAPE << 1)) | (np.minimum(nh, NH_ESCAPE).astype(np.uint32) << np.uint32(1))
+            big = nh_side_list(nh)
+        if single_hit is None:
+            single_hit = len(aln) > 0 and int(((aln["tsn"] >> np.uint32(1)) & np.uint32(NH_ESCAPE)).max()) <= 1
+        self._keep.append(aln)
+        check(lib().mm_annotate_batch(self._h, aln.ctypes.data, len(aln), big.ctypes.data if len(big) else None, len(big), int(qid_bound),
+                                      _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
 
-    def add_batch_device(self, aln_ptr: int, nh_ptr: Optional[int], n: int, qid_bound: int):
-        """Tuples already resident in HBM (e.g. torch tensors: pass .data_ptr())."""
-        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), C.c_void_p(nh_ptr) if nh_ptr else None, int(n), int(qid_bound), 1))
+    def add_batch_device(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False, big: Optional[np.ndarray] = None):
+        """Tuples already resident in HBM (e.g. a torch tensor: pass .data_ptr())."""
+        flags = _lib.MM_BATCH_ON_DEVICE | (_lib.MM_BATCH_SINGLE_HIT if single_hit else 0)
+        nb = 0 if big is None else len(big)
+        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), big.ctypes.data if nb else None, nb, int(qid_bound), flags))
+
+    def add_batch_host(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False):
+        """Packed tuples in (pinned) host memory the caller keeps alive (see the lifetime rule of mm_annotate_batch)."""
+        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), None, 0, int(qid_bound), _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
 
     def sync(self):
         check(lib().mm_sync(self._h))
@@ -377,13 +422,17 @@ class ReadsDecoder:
             raise _lib.MMError(rc, msg)
 
     def next(self, cap: int = 1 << 20):
+        """-> (tuples, NH of every tuple); the side list of the batch stays in self.last_big"""
         aln = np.empty(cap, dtype=ALN_DTYPE)
-        nh = np.empty(cap, dtype=np.uint32)
-        n = C.c_size_t(0)
-        rc = lib().mm_reader_next(self._h, aln.ctypes.data, nh.ctypes.data, cap, C.byref(n))
+        big = np.empty(max(64, min(cap, 1 << 16)), dtype=NH_BIG_DTYPE)
+        n, nb, mx = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+        rc = lib().mm_reader_next(self._h, aln.ctypes.data, cap, C.byref(n), big.ctypes.data, len(big), C.byref(nb), C.byref(mx))
         if rc != 0:
             raise _lib.MMError(rc, lib().mm_reader_error(self._h).decode(errors="replace"))
-        return aln[:n.value], nh[:n.value]
+        self.last_big = big[:nb.value].copy()
+        self.last_max_nh = int(mx.value)
+        a = aln[:n.value]
+        return a, aln_nh(a, self.last_big)
 
     def read_all(self, cap: int = 1 << 20):
         al, nl = [], []

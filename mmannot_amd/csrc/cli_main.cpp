@@ -94,6 +94,28 @@ struct GlibcRand {
   }
 };
 
+// Host staging of the tuple stream: three pinned buffers (hipHostMalloc through the C ABI).  The decoder fills one while the
+// library's copy stream drains the two submitted before it (a host buffer is free again once the second-next
+// mm_annotate_batch has returned), so H2D copies, kernels and decoding overlap and nothing waits per batch.
+struct Staging {
+  static constexpr size_t BATCH = 1 << 22;
+  mm_aln *buf[3] = {nullptr, nullptr, nullptr};
+  std::vector<mm_nh_big> big;
+  std::vector<uint64_t> hm;
+  bool ok() const { return buf[0] && buf[1] && buf[2]; }
+  Staging() { for (auto &b : buf) b = (mm_aln *) mm_host_alloc(BATCH * sizeof(mm_aln)); big.resize(1 << 16); }
+  ~Staging() { for (auto &b : buf) mm_host_free(b); }
+};
+
+// -y random across input files (sequential runs): the reference's Counter keeps `seen`, `chosenId` and `numberSeen` - all keyed
+// by read name - when it moves on to the next file (Counter::clear, mmannot.cpp:1742-1747, does not touch them), and rand() is
+// process-global, so file 2 continues file 1's sequence and a name already output in file 1 is never output again.
+struct RandomState {
+  GlibcRand rng;
+  std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> choice;   // name -> (chosenId, numberSeen) still open at the end of earlier files
+  std::unordered_map<std::string, bool> seen;                              // names output in earlier files
+};
+
 struct PendingRead {  // readCounts + rawCounts + readsIntervals entry, mmannot.cpp:1656-1660
   uint32_t remaining, raw;
   std::vector<uint8_t> regions;
@@ -256,12 +278,13 @@ int main(int argc, char **argv) {
   for (int32_t e = 0; e < E; ++e) elem_names.push_back(mm_annotation_element_name(an, e));
 
   std::map<uint64_t, std::vector<unsigned>> table;  // element set -> one column per input (TableCount::regionCounts, :1858)
-  const size_t BATCH = 1 << 22;
+  const size_t BATCH = Staging::BATCH;
   // One input file on one context.  `err` is std::cerr itself when files are taken one after the other, and a buffer that is
   // printed in command-line order afterwards when several are in flight (-t): the reference's threads interleave their
   // messages as they come; here the text is always the one a -t 1 run prints.
   std::mutex table_mu;
-  auto process_file = [&](size_t fi, mm_ctx *ctx, std::ostream &err, std::vector<mm_aln> &aln, std::vector<uint32_t> &nh, std::vector<uint64_t> &hm) -> int {
+  auto process_file = [&](size_t fi, mm_ctx *ctx, std::ostream &err, Staging &stg, RandomState &rnd) -> int {
+    std::vector<uint64_t> &hm = stg.hm;
     if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
@@ -270,9 +293,10 @@ int main(int argc, char **argv) {
     std::unordered_map<uint32_t, PendingRead> pending;
     std::map<uint64_t, double> host_counts;
     std::map<std::vector<uint32_t>, unsigned> interval_counts;      // intervalCounts, mmannot.cpp:1659
-    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> rnd_choice;   // chosenId / numberSeen, mmannot.cpp:1661
-    std::vector<bool> rnd_seen;                                      // seen, mmannot.cpp:1662
-    GlibcRand grand;
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> rnd_choice;   // chosenId / numberSeen, mmannot.cpp:1661 (this file's name ids)
+    std::vector<uint8_t> rnd_seen;                                   // seen, mmannot.cpp:1662: bit 0 = seen, bit 1 = earlier files consulted
+    GlibcRand &grand = rnd.rng;
+    const bool rnd_carry = !rnd.choice.empty() || !rnd.seen.empty();
     uint64_t h_reads = 0, h_rescued = 0;
     auto print_read_stats = [&](uint32_t qid, unsigned nhits, std::vector<uint8_t> &regions) -> void {  // :474-493 + rescue :497-509
       if (!read_stats) return;
@@ -307,16 +331,21 @@ int main(int argc, char **argv) {
     };
     std::vector<uint32_t> hi_cnt, hi_idx;
     uint64_t cpt = 0;
-    for (;;) {
-      size_t n = 0;
+    for (size_t batch_no = 0;; ++batch_no) {
+      size_t n = 0, n_big = 0;
+      uint32_t max_nh = 0;
+      mm_aln *aln = stg.buf[batch_no % 3];
       const auto t0 = now();
-      rc = mm_reader_next(rd, aln.data(), nh.data(), BATCH, &n);
+      rc = mm_reader_next(rd, aln, BATCH, &n, stg.big.data(), stg.big.size(), &n_big, &max_nh);
       err << mm_reader_take_log(rd);
       if (rc != MM_OK) { err << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
       const auto t1 = now();
       { std::lock_guard<std::mutex> lk(table_mu); t_decode += secs(t0, t1); n_records += n; }
       if (n == 0) break;
-      if (mm_annotate_batch(ctx, aln.data(), nh.data(), n, mm_reader_qid_bound(rd), 0) != MM_OK || mm_sync(ctx) != MM_OK) {
+      // asynchronous: the copy and the kernels of this batch run while the next one is decoded; only the sequential side
+      // channels (-m / -M / -y random), which read per-hit results back, wait for the batch
+      if (mm_annotate_batch(ctx, aln, n, stg.big.data(), n_big, mm_reader_qid_bound(rd), max_nh <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK ||
+          (host_book && mm_sync(ctx) != MM_OK)) {
         err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
       }
       { std::lock_guard<std::mutex> lk(table_mu); t_device += secs(t1, now()); }
@@ -330,14 +359,16 @@ int main(int argc, char **argv) {
           hi_idx.resize(hi_total ? hi_total : 1);
           if (hi_total && mm_get_hit_intervals(ctx, hi_cnt.data(), hi_idx.data(), hi_total, &hi_total) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
         }
-        size_t hi_off = 0;
+        size_t hi_off = 0, big_at = 0;
         for (size_t i = 0; i < n; ++i) {
           if (hm[i] == ~0ull) continue;            // skipped by -y unique
           std::vector<uint8_t> regions;
           for (int e = 0; e < E; ++e) if (hm[i] >> e & 1) regions.push_back((uint8_t) e);
           std::vector<uint32_t> intervals;
           if (interval_stats) { intervals.assign(hi_idx.begin() + hi_off, hi_idx.begin() + hi_off + hi_cnt[i]); hi_off += hi_cnt[i]; }
-          const uint32_t q = aln[i].qid, h = nh[i];
+          uint32_t h = MM_ALN_NH_FIELD(aln[i].tsn);
+          if (h == MM_ALN_NH_ESCAPE) { while (big_at < n_big && stg.big[big_at].index < i) ++big_at; h = stg.big[big_at].nh; }
+          const uint32_t q = aln[i].qid;
           if (h > 1 && strategy == MM_STRAT_DEFAULT) {   // :1669-1702
             auto it = pending.find(q);
             if (it == pending.end()) { pending[q] = PendingRead{h - 1, h, regions, intervals}; ++h_reads; }
@@ -360,13 +391,20 @@ int main(int argc, char **argv) {
               bool output = true;
               if (strategy == MM_STRAT_RANDOM) {         // :1706-1726, libc rand() without srand, as the reference
                 output = false;
-                if (q >= rnd_seen.size()) rnd_seen.resize((size_t) q + 1024, false);
-                if (!rnd_seen[q]) {
+                if (q >= rnd_seen.size()) rnd_seen.resize((size_t) q + 1024, 0);
+                if (rnd_carry && !(rnd_seen[q] & 2)) {   // first time this file meets the name: what did earlier files leave for it?
+                  rnd_seen[q] |= 2;
+                  const std::string nm = mm_reader_name(rd, q);
+                  if (rnd.seen.count(nm)) rnd_seen[q] |= 1;
+                  auto pc = rnd.choice.find(nm);
+                  if (pc != rnd.choice.end()) { rnd_choice[q] = pc->second; rnd.choice.erase(pc); }
+                }
+                if (!(rnd_seen[q] & 1)) {
                   auto pc = rnd_choice.find(q);
                   uint32_t chosen, seen_n;
                   if (pc == rnd_choice.end()) { chosen = h ? (uint32_t) (grand.next() % h) : 0u; seen_n = 0; rnd_choice[q] = std::make_pair(chosen, seen_n); }
                   else { chosen = pc->second.first; seen_n = ++pc->second.second; }
-                  if (seen_n == chosen) { output = true; rnd_choice.erase(q); rnd_seen[q] = true; }
+                  if (seen_n == chosen) { output = true; rnd_choice.erase(q); rnd_seen[q] |= 1; }
                 }
               }
               if (output) {
@@ -446,18 +484,22 @@ int main(int argc, char **argv) {
         col[fi] = mm_round_to_uint(sums[r]);
       }
     }
+    if (strategy == MM_STRAT_RANDOM && n_inputs > 1) {   // hand this file's name-keyed state on to the next file
+      for (size_t q = 0; q < rnd_seen.size(); ++q) if (rnd_seen[q] & 1) rnd.seen[mm_reader_name(rd, (uint32_t) q)] = true;
+      for (auto &e : rnd_choice) rnd.choice[mm_reader_name(rd, e.first)] = e.second;
+    }
     mm_reader_close(rd);
     return 0;
   };
   const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t) n_threads, n_inputs));
   int rc_all = 0;
   if (n_workers == 1) {
-    std::vector<mm_aln> aln(BATCH);
-    std::vector<uint32_t> nh(BATCH);
-    std::vector<uint64_t> hm;
+    Staging stg;
+    RandomState rnd;
     mm_ctx *ctx = nullptr;
+    if (!stg.ok()) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     if (mm_ctx_create(&ctx, indices[0], &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
-    for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, ctx, std::cerr, aln, nh, hm);
+    for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, ctx, std::cerr, stg, rnd);
     mm_ctx_destroy(ctx);
   } else {
     // -t n: the reference runs n threads over the input files (mmannot.cpp:2117-2143); here n files are in flight, each on its
@@ -468,16 +510,17 @@ int main(int argc, char **argv) {
     std::vector<std::thread> workers;
     for (size_t w = 0; w < n_workers; ++w)
       workers.emplace_back([&, w]() {
-        std::vector<mm_aln> aln(BATCH);
-        std::vector<uint32_t> nh(BATCH);
-        std::vector<uint64_t> hm;
+        // (-y random with several files in flight: every worker replays its own rand() sequence per file - the reference's threads
+        // race on one process-global rand() there, so no particular interleaving is "the" answer)
+        Staging stg;
         mm_ctx *ctx = nullptr;
-        const bool ok = mm_ctx_create(&ctx, indices[w % indices.size()], &opt, nullptr) == MM_OK;
+        const bool ok = stg.ok() && mm_ctx_create(&ctx, indices[w % indices.size()], &opt, nullptr) == MM_OK;
         for (;;) {
           const size_t fi = next_file.fetch_add(1);
           if (fi >= n_inputs) break;
           if (!ok) { errs[fi] << "mmannot-amd: " << mm_last_error() << std::endl; rcs[fi] = EXIT_FAILURE; continue; }
-          rcs[fi] = process_file(fi, ctx, errs[fi], aln, nh, hm);
+          RandomState rnd;
+          rcs[fi] = process_file(fi, ctx, errs[fi], stg, rnd);
         }
         if (ctx) mm_ctx_destroy(ctx);
       });

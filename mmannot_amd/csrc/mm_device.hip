@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
   if (threadIdx.x < 3) sq[threadIdx.x] = 0;
   __syncthreads();
-  u32 qinv = 0, qmax = 0, big = 0;
+  u32 qinv = 0, qmax = 0, bigNh = 0;
   const u32 lane = threadIdx.x & 63;
   u32 cHits = 0, cReads = 0, cUnique = 0, cAmb = 0, cMulti = 0, cUnas = 0;  // wave-uniform
   u32 walked = 0;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     if (grouped) {
       key = (u32) a.w;
       qinv = max(qinv, ~key); qmax = max(qmax, key);
-      if (nh >= 0xFFFFu) big = 1;
+      if (nh >= 0xFFFFu) bigNh = 1;
     }
     // counting / slot lookup, per lane through the workgroup's LDS tables:
     //   per-hit branch (default/unique): the set is counted now;
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     }
   }
   if (grouped_strategy && gkey) {
-    for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); big |= __shfl_down(big, off); }
-    if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (big) atomicOr(&sq[2], 1u); }
+    for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); bigNh |= __shfl_down(bigNh, off); }
+    if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (bigNh) atomicOr(&sq[2], 1u); }
   }
   if (lane == 0) {
     atomicAdd(&sstat[MM_STAT_HITS], cHits); atomicAdd(&sstat[MM_STAT_READS], cReads);
@@ -1555,7 +1555,7 @@ struct mm_ctx {
   int big_cur = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool consumed_valid[2] = {false, false};
+  bool consumed_valid[2] = {false, false}, copied_valid[2] = {false, false};
   int cur = 0;
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
@@ -1585,7 +1585,7 @@ struct PhaseTimer {  // records an event pair around a group of launches when pr
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
   hipStream_t stream_override = nullptr;
   PhaseTimer(mm_ctx *c_, int ph) : c(c_), phase(ph) {
-    if ((c->profiling == 1 || (c->profiling == 2 && ph == MM_PHASE_PROBE)) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+    if ((c->profiling == 1 || (c->profiling == 2 && (ph == MM_PHASE_PROBE || ph == MM_PHASE_H2D))) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
       (void) hipEventRecord(a, c->stream);
   }
   void restart() { if (a) (void) hipEventRecord(a, stream_override ? stream_override : c->stream); }
@@ -1826,7 +1826,7 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 }
 
 static void ctx_free_batch(mm_ctx *c) {
-  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); c->d_alnBuf[b] = nullptr; c->consumed_valid[b] = false; }
+  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); c->d_alnBuf[b] = nullptr; c->consumed_valid[b] = false; c->copied_valid[b] = false; }
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
@@ -2053,6 +2053,9 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
     // copy stream: wait until the kernels that last read this staging set are done, copy, signal; the compute stream
     // waits for the signal.  With two sets the copy of this batch overlaps the kernels of the previous one.
     const int b = c->cur; c->cur ^= 1; staged = b;
+    // (host side: the copy that used this set two batches ago has finished - that batch's host buffer is free again when this call
+    // returns, which is the lifetime rule of include/mmannot_amd.h and keeps the host at most two batches ahead of the device)
+    if (c->copied_valid[b]) HIPCHK(hipEventSynchronize(c->ev_copied[b]));
     if (c->consumed_valid[b]) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[b], 0));
     {
       PhaseTimer t(c, MM_PHASE_H2D);
@@ -2060,7 +2063,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       t.restart();
       HIPCHK(hipMemcpyAsync(c->d_alnBuf[b], aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->copy_stream));
     }
-    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy_stream));
+    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy_stream)); c->copied_valid[b] = true;
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
     c->d_aln = c->d_alnBuf[b];
     d_aln = c->d_aln;

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-        "config", "roofline"}
+        "config", "roofline", "kernel_only", "h2d"}
 
 
 def _json_lines(out):
@@ -29,6 +29,10 @@ def test_single_rank_contract(gpu_lib):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["value"] > 0 and d["stats"]["nHits"] == 4 * (1 << 20)
+    # `value` is the rate from pinned host tuples (copies inside the timed region); the HBM-resident rate is reported beside it
+    h, k = d["h2d"], d["kernel_only"]
+    assert h["bound"] == "pcie" and h["unit"] == "GB/s" and h["alg_bytes_per_alignment"] == 16.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
+    assert k["value"] > 0 and "pinned host" in d["config"]["input"]
 
 
 @pytest.mark.timeout(900)

@@ -24,15 +24,14 @@ def run_stream(mm, index, cfg, *, total, batch, seed, read_len, nh_max, scatter,
     stream = torch.cuda.current_stream().cuda_stream
     ctr = mm.Counter(index, overlap=overlap, strandedness=strand, strategy=strategy, stream=stream)
     a = torch.empty((batch, 4), dtype=torch.int32, device=dev)
-    h = torch.empty(batch, dtype=torch.int32, device=dev) if nh_max > 1 else None
     gpt = (nh_max / (nh_max * (nh_max + 1) / 2.0)) if nh_max > 1 else 1.0
     qb = int(total * gpt) + nh_max + 2
     done = 0
     while done < total:
         n = min(batch, total - done)
         p = _lib.SynthParams(seed, done, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
-        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), h.data_ptr() if h is not None else None, n, C.byref(p), stream))
-        ctr.add_batch_device(a.data_ptr(), h.data_ptr() if h is not None else None, n, qb)
+        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), n, C.byref(p), stream))
+        ctr.add_batch_device(a.data_ptr(), n, qb, single_hit=(nh_max == 1))
         ctr.sync()            # the tuple buffer is reused for the next batch
         done += n
     ctr.flush()

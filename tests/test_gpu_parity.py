@@ -151,7 +151,10 @@ def test_huge_nh_payload_by_index(gpu_lib, oracle, shuffle):
     reads = sr.random_reads(rng, ix, n=24000, nchr=3, maxpos=100000, nh_max=6, shuffle=shuffle)
     nh = reads["nh"].copy()
     q = reads["qid"]
-    for name, val in ((int(q[100]), 70000), (int(q[9000]), 65535), (int(q[17000]), 4000000000)):   # whole names get the huge value
+    # whole names get the huge value; 2046 is the largest NH the tuple's own field holds, 2047 and 5000 take the side list
+    # without switching the payload, the rest switch it
+    for name, val in ((int(q[100]), 70000), (int(q[9000]), 65535), (int(q[17000]), 4000000000), (int(q[3000]), 2046), (int(q[5000]), 2047),
+                      (int(q[12000]), 5000), (int(q[20000]), 65534)):
         nh[q == name] = val
     reads = dict(reads, nh=nh)
     ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy="default")
@@ -200,16 +203,16 @@ def test_synth_generator_twin(gpu_lib):
     for nh_max, sc, first, pair in ((1, 0, 0, 0), (20, 0, 12345, 0), (20, 10, 1 << 20, 0), (5, 16, 777, 0), (1, 0, 4321, 250)):
         n = 100_000
         aln = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
-        nh = torch.zeros(n, dtype=torch.int32, device="cuda")
         p = _lib.SynthParams(42, first, 100, nh_max, len(chr_len), chr_len.ctypes.data, sc, pair)
-        _lib.check(_lib.lib().mm_synth_fill(aln.data_ptr(), nh.data_ptr(), n, C.byref(p), torch.cuda.current_stream().cuda_stream))
+        _lib.check(_lib.lib().mm_synth_fill(aln.data_ptr(), n, C.byref(p), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
-        a = aln.cpu().numpy().view(np.uint32)
+        a = np.ascontiguousarray(aln.cpu().numpy()).view(mm.ALN_DTYPE).reshape(-1)
         t = sr.synth_tuples(42, first, n, 100, nh_max, chr_len, sc, pair)
-        assert (a[:, 0].astype(np.int64) == t["start"]).all() and (a[:, 1].astype(np.int64) == t["end"]).all()
-        assert ((a[:, 2] >> 1).astype(np.int64) - 1 == t["tid"]).all() and ((a[:, 2] & 1) == t["strand"]).all()
-        assert (a[:, 3].astype(np.int64) == t["qid"]).all()
-        assert (nh.cpu().numpy().view(np.uint32) == t["nh"]).all()
+        assert (a["start"].astype(np.int64) == t["start"]).all() and (a["end"].astype(np.int64) == t["end"]).all()
+        assert (mm.aln_tid(a) == t["tid"]).all() and (mm.aln_strand(a) == t["strand"]).all()
+        assert (a["qid"].astype(np.int64) == t["qid"]).all()
+        assert (mm.aln_nh(a) == t["nh"]).all()
+        assert a.tobytes() == mm.pack_alignments(t["tid"], t["start"], t["end"], t["strand"], t["qid"], t["nh"]).tobytes()
 
 
 @pytest.mark.parametrize("nh_max,strand,l", [(100, "F", -1.0), (3, "U", 0.5), (1, "R", -1.0)])

@@ -51,7 +51,7 @@ def test_kat_host_plus_oracle(oracle, name):
         assert (aln["end"][keep].astype(np.int64) == want_end).all()
         assert (nh[keep] == np.array(h["nh"], dtype=np.int64)).all()
         if c["variant"] == "patched" and len(aln):
-            assert ((aln["tid_strand"][keep] & 1) == np.array(h["strand"])).all()
+            assert (api.aln_strand(aln)[keep] == np.array(h["strand"])).all()
         names = [dec.name(int(q)) for q in aln["qid"]] if False else None
         # read names -> dense ids in first-appearance order
         want_q = {}
@@ -70,7 +70,7 @@ def test_kat_host_plus_oracle(oracle, name):
         cfg = oracle.ConfigDesc([oracle.Element(*(lambda nm, sd, ln: (nm.split(":")[0], ":".join(nm.split(":")[1:]), sd, ln))(
             (n[:-4] if n.endswith((" (+)", " (-)")) else n), int(s), int(l))) for n, s, l in zip(an.names, an.elem_strand, an.line_of)])
         ix = dict(chr=an.chr, start=an.start, end=an.end, type=an.type, strand=an.strand, n_chromosomes=len(an.chromosomes))
-        rd = dict(tid=(aln["tid_strand"] >> 1).astype(np.int64) - 1, start=aln["start"], end=aln["end"], strand=aln["tid_strand"] & 1, nh=nh, qid=aln["qid"])
+        rd = dict(tid=api.aln_tid(aln), start=aln["start"], end=aln["end"], strand=api.aln_strand(aln), nh=nh, qid=aln["qid"])
         r = oracle.run(cfg, ix, rd, overlap=o["overlap"], strandedness=o["strandedness"], strategy=o["strategy"], want_hit_mask=True)
         assert oracle.format_table(cfg, r.row_mask, r.row_count, "r") == c["table"]
         assert oracle.format_stats(r.stats, "$D/" + os.path.basename(reads)) in c["stderr"]

@@ -42,7 +42,7 @@ def test_host_plus_oracle(oracle, inputs, name):
         aln, nh = dec.read_all()
         desc = oracle.ConfigDesc([oracle.Element(e.source, e.type, e.strand, e.line) for e in an.config().elements])
         ix = dict(chr=an.chr, start=an.start, end=an.end, type=an.type, strand=an.strand, n_chromosomes=len(an.chromosomes))
-        rd = dict(tid=(aln["tid_strand"] >> 1).astype(np.int64) - 1, start=aln["start"], end=aln["end"], strand=aln["tid_strand"] & 1, nh=nh, qid=aln["qid"])
+        rd = dict(tid=api.aln_tid(aln), start=aln["start"], end=aln["end"], strand=api.aln_strand(aln), nh=nh, qid=aln["qid"])
         r = oracle.run(desc, ix, rd, overlap=o["overlap"], strandedness=o["strandedness"], strategy=o["strategy"])
         assert oracle.format_table(desc, r.row_mask, r.row_count, "r") == c["table"], c["args"]
         assert oracle.format_stats(r.stats, "$D/r.bam") in c["stderr"]

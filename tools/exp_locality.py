@@ -17,7 +17,7 @@ for wl in ("c2", "c3"):
         chr_len = np.ascontiguousarray(an.chr_len, dtype=np.int64)
         p = _lib.SynthParams(5, 0, read_len, 1, len(chr_len), chr_len.ctypes.data, 0)
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), None, B, C.byref(p), st)); torch.cuda.synchronize()
+        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), B, C.byref(p), st)); torch.cuda.synchronize()
         key = (a[:, 2].to(torch.int64) >> 1) * (1 << 32) + a[:, 0].to(torch.int64)
         order_full = torch.argsort(key)
         cum = np.concatenate([[0], np.cumsum(chr_len)])
@@ -29,9 +29,9 @@ for wl in ("c2", "c3"):
         variants = {"file": a, "bucket256": a[order_b256].contiguous(), "bucket4096": a[order_b4k].contiguous(), "sorted": a[order_full].contiguous()}
         for name, t in variants.items():
             ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy="default", stream=st)
-            for _ in range(2): ctr.add_batch_device(t.data_ptr(), None, B, 1)
+            for _ in range(2): ctr.add_batch_device(t.data_ptr(), B, 1, single_hit=True)
             ctr.sync(); ctr.set_profiling(True)
-            for _ in range(5): ctr.add_batch_device(t.data_ptr(), None, B, 1)
+            for _ in range(5): ctr.add_batch_device(t.data_ptr(), B, 1, single_hit=True)
             ms, n = ctr.phase_ms()["probe"]
             ctr.flush(); s = ctr.stats()
             print(wl, "shift", index.info()["bin_shift"], name, "probe ms %.3f" % (ms / n), "G aln/s %.1f" % (B / (ms / n) / 1e6), s["nUnassigned"], flush=True)
