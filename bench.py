@@ -266,6 +266,28 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores() -> int:
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU
+    box hands each job a share of the host; more processes than that only time-slice)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota, period = txt[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(quota) // period))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args, an, wl, chr_len):
     """The CPU restatement of the path (oracle/mm_oracle.c, kind "port", one thread) on a prefix of rank 0's stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -315,11 +337,7 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     from oracle import mm_oracle as mo
     read_len, nh_max, scatter, strategy = wl["read_len"], wl["nh_max"], wl["scatter"], wl["strategy"]
     flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else []) + (["-y", strategy] if strategy != "default" else [])
-    try:
-        S = len(os.sched_getaffinity(0))
-    except AttributeError:
-        S = os.cpu_count() or 1
-    S = max(1, S)
+    S = host_cores()
     n = 1 << (21 if S <= 32 else 20)     # bounded sample: S shards, about 1-2 s of reference time each
     d = tempfile.mkdtemp(prefix="mmbench")
     gtf = os.path.join(d, "a.gtf"); open(gtf, "w").write(synth.gtf_text(an))

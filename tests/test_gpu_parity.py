@@ -140,10 +140,12 @@ def test_name_grouped_input(gpu_lib, oracle):
 
 
 @pytest.mark.parametrize("shuffle", [True, False])
-def test_huge_nh_payload_by_index(gpu_lib, oracle, shuffle):
-    """A batch holding an NH >= 65535 cannot carry (slot, NH) in 32 bits: the sort payload becomes the record index and the
+@pytest.mark.parametrize("vals", ["beyond_payload", "beyond_field"])
+def test_huge_nh_payload_by_index(gpu_lib, oracle, shuffle, vals):
+    """NH travels in an 11-bit field of the tuple; larger values go through the batch's side list (mm_nh_big).  A batch holding
+    an NH >= 65535 cannot carry (slot, NH) in the 32-bit sort payload either: the payload becomes the record index and the
     merge kernel reads the element set and NH through it (INFO_BIGNH).  Same answers as the oracle, in interleaved and in
-    name-grouped order, across batches with and without such a record."""
+    name-grouped order, across batches with and without such records."""
     mm = gpu_lib
     rng = np.random.default_rng(4242)
     desc = sr.random_config(rng, n_lines=5, max_per_line=3)
@@ -151,18 +153,47 @@ def test_huge_nh_payload_by_index(gpu_lib, oracle, shuffle):
     reads = sr.random_reads(rng, ix, n=24000, nchr=3, maxpos=100000, nh_max=6, shuffle=shuffle)
     nh = reads["nh"].copy()
     q = reads["qid"]
-    # whole names get the huge value; 2046 is the largest NH the tuple's own field holds, 2047 and 5000 take the side list
-    # without switching the payload, the rest switch it
-    for name, val in ((int(q[100]), 70000), (int(q[9000]), 65535), (int(q[17000]), 4000000000), (int(q[3000]), 2046), (int(q[5000]), 2047),
-                      (int(q[12000]), 5000), (int(q[20000]), 65534)):
-        nh[q == name] = val
+    # whole names get the value; 2046 is the largest NH the tuple's own field holds
+    plan = {"beyond_payload": ((100, 70000), (9000, 65535), (17000, 4000000000), (3000, 2046), (5000, 2047), (12000, 5000), (20000, 65534)),
+            "beyond_field": ((100, 2046), (3000, 2047), (9000, 2048), (12000, 5000), (17000, 65534), (20000, 40000))}[vals]
+    for pos, val in plan:
+        nh[q == int(q[pos])] = val
     reads = dict(reads, nh=nh)
-    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy="default")
-    cfg = to_cfg(mm, desc)
-    for batches in (1, 3):
-        r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="F", strategy="default", batches=batches, keep=False)
-        assert r["stats"] == ref.stats
-        assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+    assert len(mm.nh_side_list(nh)) > 0
+    for strategy in ("default", "ratio"):
+        ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy=strategy)
+        cfg = to_cfg(mm, desc)
+        for batches in (1, 3):
+            r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="F", strategy=strategy, batches=batches, keep=False)
+            assert r["stats"] == ref.stats
+            assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+
+
+def test_nh_side_list_errors(gpu_lib):
+    """The side list is validated: an escaped tuple without an entry, and MM_BATCH_SINGLE_HIT broken, are errors at the next sync."""
+    mm = gpu_lib
+    rng = np.random.default_rng(3)
+    desc = sr.random_config(rng, 3, 1)
+    ix = sr.random_index(rng, desc.E, nchr=1, n=20, maxpos=20000)
+    index = mm.IntervalIndex(to_cfg(mm, desc), ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], 1)
+    n = 100
+    nh = np.full(n, 3, dtype=np.uint32); nh[17] = 9999
+    aln = mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n), nh)
+    ctr = mm.Counter(index)
+    ctr.add_batch(aln, None, n)                     # tuple 17 escapes, no side list given
+    with pytest.raises(mm.MMError):
+        ctr.sync()
+    ctr.close()
+    ctr = mm.Counter(index)
+    ctr.add_batch(aln, nh, n, single_hit=False)     # with the list: fine
+    ctr.sync(); ctr.close()
+    ctr = mm.Counter(index)
+    with pytest.raises(mm.MMError):                 # a side list together with the single-hit promise is refused at once
+        ctr.add_batch(aln, nh, n, single_hit=True)
+    ctr.add_batch(mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n), np.full(n, 2)), None, n, single_hit=True)
+    with pytest.raises(mm.MMError):                 # promise broken: NH = 2 everywhere
+        ctr.sync()
+    ctr.close(); index.close()
 
 
 def test_empty_and_edge_batches(gpu_lib, oracle):
