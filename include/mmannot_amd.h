@@ -177,6 +177,25 @@ int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
  * batches in order), and hands its mm_get_rows on to rank r+1. */
 int mm_set_row_sums(mm_ctx *ctx, const uint64_t *masks, const double *sums, size_t n);
 int mm_ratio_resolve(mm_ctx *ctx);
+int mm_ratio_resolve_n(mm_ctx *ctx, size_t max_runs);   /* replays only the first max_runs parked batches */
+size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet replayed */
+
+/* ---- one input on several GPUs (replaces the reference's thread-per-file pool, mmannot.cpp:2117-2143, which can only
+ * spread whole files).  One context per device, each on its own copy of the index.
+ * mm_partition (host): deals the tuples of one decoded batch out by qid mod n_parts, file order kept inside each part, read names
+ * renumbered qid / n_parts (dense per part; the caller passes ceil(qid_bound / n_parts) on).  out[p] needs room for n tuples,
+ * out_big[p] for big_cap entries; out_max_nh[p] (may be NULL) = the part's largest NH.  Every hit of a name lands in one part,
+ * which is what the multi-hit countdown of -y default needs (mmannot.cpp:1669-1701); -y unique may use it too.
+ * -y ratio instead sends whole batches round-robin (batch j to context j mod n, contexts created with defer_ratio): its per-row
+ * double sums are file-order dependent (mmannot.cpp:1730).
+ * mm_merge (host, after mm_finalize on every context): the input's table and counters.  default / unique: rows and counters add
+ * up.  ratio: the parked accumulations are replayed in file order, each context starting from the bit patterns its predecessor
+ * ended with.  masks NULL: only *n_rows and stats.  (Ranks that are separate processes merge with an all_gather of the keys and
+ * an all_reduce of the dense count vector over RCCL instead: mmannot_amd/dist.py.) */
+int mm_partition(const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, int n_parts, mm_aln *const *out, size_t *out_n,
+                 mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh);
+int mm_merge(mm_ctx *const *ctxs, int n_ctx, int strategy, uint64_t *masks, double *sums, size_t cap, size_t *n_rows,
+             uint64_t stats[MM_N_STATS]);
 
 /* Live timing with HIP events recorded on the context's stream around each phase of
  * mm_annotate_batch / mm_finalize (bench.py's roofline leg).  on = 0 off (default), 1 every phase, 2 the probe phase and the

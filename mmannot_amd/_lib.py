@@ -73,6 +73,11 @@ SYMBOLS = {
     "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mm_set_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
+    "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mm_ratio_pending": (C.c_size_t, [C.c_void_p]),
+    "mm_partition": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                               C.c_void_p]),
+    "mm_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mm_round_to_uint": (C.c_uint32, [C.c_double]),

@@ -261,7 +261,9 @@ int main(int argc, char **argv) {
     if (device_given || n_threads <= 1 || n_inputs <= 1) devices.push_back(device);
     else { const int nd = std::max(1, mm_device_count()); for (int d = 0; d < nd; ++d) devices.push_back(d); }
   }
-  if (devices.size() > n_inputs) devices.resize(std::max<size_t>(1, n_inputs));
+  // several devices for ONE input file: its reads are sharded over them (not with the sequential side channels -m / -M / -y random)
+  const bool shard_one_input = n_inputs == 1 && devices.size() > 1 && !host_book;
+  if (!shard_one_input && devices.size() > n_inputs) devices.resize(std::max<size_t>(1, n_inputs));
   std::vector<mm_index *> indices;
   { const auto t0 = now();
   for (int d : devices) {
@@ -283,6 +285,47 @@ int main(int argc, char **argv) {
   // printed in command-line order afterwards when several are in flight (-t): the reference's threads interleave their
   // messages as they come; here the text is always the one a -t 1 run prints.
   std::mutex table_mu;
+  // Counter::dump (:1806-1818, the -M file :1819-1850) and TableCount::addCounter (:1861-1876) for one input file
+  auto report = [&](size_t fi, const uint64_t *st, const std::vector<uint64_t> &masks, const std::vector<double> &sums, std::ostream &err,
+                    std::map<std::vector<uint32_t>, unsigned> *interval_counts) {
+    err << "Results for " << reads[fi] << ":" << std::endl;
+    if (st[MM_STAT_HITS] == 0) err << "\tNo hit." << std::endl;
+    else {
+      err << "\t# reads:                       " << commas(st[MM_STAT_READS]) << "\n"
+                << stat_line(st[MM_STAT_UNIQUE], "# uniquely mapped reads:       ", st[MM_STAT_READS])
+                << stat_line(st[MM_STAT_RESCUED], "# multi-mapping rescued reads: ", st[MM_STAT_READS])
+                << "\t# hits:                        " << commas(st[MM_STAT_HITS]) << "\n"
+                << stat_line(st[MM_STAT_AMBIGUOUS], "# ambiguous hits:              ", st[MM_STAT_HITS])
+                << stat_line(st[MM_STAT_UNASSIGNED], "# unassigned hits:             ", st[MM_STAT_HITS]);
+    }
+    if (interval_stats && interval_counts) {             // Counter::dump, :1819-1850
+      const uint8_t *iv_type = nullptr;
+      mm_annotation_intervals(an, nullptr, nullptr, nullptr, &iv_type, nullptr);
+      std::vector<std::pair<std::string, unsigned>> lines;
+      for (auto &p : *interval_counts) {
+        std::vector<std::string> nm;
+        for (uint32_t i : p.first) nm.push_back(std::string(mm_annotation_interval_id(an, i)) + " (" + elem_names[iv_type[i]] + ")");
+        std::sort(nm.begin(), nm.end());
+        std::string joined;
+        for (size_t k = 0; k < nm.size(); ++k) joined += (k ? " -- " : "") + nm[k];
+        lines.emplace_back(joined, p.second);
+      }
+      std::sort(lines.begin(), lines.end());
+      std::string cur;
+      unsigned count = 0;
+      for (auto &ln : lines) {
+        if (ln.first == cur) count += ln.second;
+        else { if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n"; cur = ln.first; count = ln.second; }
+      }
+      if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n";
+    }
+    std::lock_guard<std::mutex> lk(table_mu);
+    for (size_t r = 0; r < masks.size(); ++r) {          // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
+      auto &col = table[masks[r]];
+      if (col.empty()) col.assign(n_inputs, 0);
+      col[fi] = mm_round_to_uint(sums[r]);
+    }
+  };
   auto process_file = [&](size_t fi, mm_ctx *ctx, std::ostream &err, Staging &stg, RandomState &rnd) -> int {
     std::vector<uint64_t> &hm = stg.hm;
     if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
@@ -444,46 +487,7 @@ int main(int argc, char **argv) {
       masks.resize(nr); sums.resize(nr);
       if (nr && mm_get_rows(ctx, masks.data(), sums.data(), nr, &nr) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     }
-    // Counter::dump, :1806-1818
-    err << "Results for " << reads[fi] << ":" << std::endl;
-    if (st[MM_STAT_HITS] == 0) err << "\tNo hit." << std::endl;
-    else {
-      err << "\t# reads:                       " << commas(st[MM_STAT_READS]) << "\n"
-                << stat_line(st[MM_STAT_UNIQUE], "# uniquely mapped reads:       ", st[MM_STAT_READS])
-                << stat_line(st[MM_STAT_RESCUED], "# multi-mapping rescued reads: ", st[MM_STAT_READS])
-                << "\t# hits:                        " << commas(st[MM_STAT_HITS]) << "\n"
-                << stat_line(st[MM_STAT_AMBIGUOUS], "# ambiguous hits:              ", st[MM_STAT_HITS])
-                << stat_line(st[MM_STAT_UNASSIGNED], "# unassigned hits:             ", st[MM_STAT_HITS]);
-    }
-    if (interval_stats) {                                // Counter::dump, :1819-1850
-      const uint8_t *iv_type = nullptr;
-      mm_annotation_intervals(an, nullptr, nullptr, nullptr, &iv_type, nullptr);
-      std::vector<std::pair<std::string, unsigned>> lines;
-      for (auto &p : interval_counts) {
-        std::vector<std::string> nm;
-        for (uint32_t i : p.first) nm.push_back(std::string(mm_annotation_interval_id(an, i)) + " (" + elem_names[iv_type[i]] + ")");
-        std::sort(nm.begin(), nm.end());
-        std::string joined;
-        for (size_t k = 0; k < nm.size(); ++k) joined += (k ? " -- " : "") + nm[k];
-        lines.emplace_back(joined, p.second);
-      }
-      std::sort(lines.begin(), lines.end());
-      std::string cur;
-      unsigned count = 0;
-      for (auto &ln : lines) {
-        if (ln.first == cur) count += ln.second;
-        else { if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n"; cur = ln.first; count = ln.second; }
-      }
-      if (!cur.empty()) interval_stats_out << cur << "\t" << count << "\n";
-    }
-    {
-      std::lock_guard<std::mutex> lk(table_mu);
-      for (size_t r = 0; r < masks.size(); ++r) {        // TableCount::addCounter, :1861-1876 (column = file index, not completion order)
-        auto &col = table[masks[r]];
-        if (col.empty()) col.assign(n_inputs, 0);
-        col[fi] = mm_round_to_uint(sums[r]);
-      }
-    }
+    report(fi, st, masks, sums, err, &interval_counts);
     if (strategy == MM_STRAT_RANDOM && n_inputs > 1) {   // hand this file's name-keyed state on to the next file
       for (size_t q = 0; q < rnd_seen.size(); ++q) if (rnd_seen[q] & 1) rnd.seen[mm_reader_name(rd, (uint32_t) q)] = true;
       for (auto &e : rnd_choice) rnd.choice[mm_reader_name(rd, e.first)] = e.second;
@@ -491,9 +495,86 @@ int main(int argc, char **argv) {
     mm_reader_close(rd);
     return 0;
   };
+  // One input file on several devices (--devices a,b,... with a single -r file).  -y default / unique: the tuples
+  // of every decoded batch are dealt out by read name (mm_partition), so all hits of a name meet on one device; -y ratio: whole
+  // batches go round-robin and the file-order double sums are chained when the file ends (mm_merge).  Same table and the same
+  // stderr block as one device.
+  auto process_file_multi = [&](size_t fi, std::vector<mm_ctx *> &ctxs, std::ostream &err) -> int {
+    const size_t N = ctxs.size();
+    for (mm_ctx *c : ctxs) if (mm_reset(c) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    mm_reader *rd = nullptr;
+    int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, false);
+    if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+    std::vector<Staging> stg(N);                    // per device: three pinned buffers of a full batch
+    Staging decode;                                 // where the decoder writes before the batch is dealt out
+    for (auto &g : stg) if (!g.ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    if (!decode.ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    std::vector<size_t> submitted(N, 0), part_n(N), part_nbig(N);
+    std::vector<uint32_t> part_max(N);
+    std::vector<mm_aln *> part_out(N);
+    std::vector<mm_nh_big *> part_big(N);
+    const bool ratio = strategy == MM_STRAT_RATIO;
+    uint64_t cpt = 0;
+    for (size_t batch_no = 0;; ++batch_no) {
+      size_t n = 0, n_big = 0;
+      uint32_t max_nh = 0;
+      const size_t dr = batch_no % N;              // -y ratio: the device this whole batch goes to
+      mm_aln *aln = ratio ? stg[dr].buf[submitted[dr] % 3] : decode.buf[0];
+      std::vector<mm_nh_big> &big = ratio ? stg[dr].big : decode.big;
+      const auto t0 = now();
+      rc = mm_reader_next(rd, aln, BATCH, &n, big.data(), big.size(), &n_big, &max_nh);
+      err << mm_reader_take_log(rd);
+      if (rc != MM_OK) { err << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
+      const auto t1 = now();
+      t_decode += secs(t0, t1); n_records += n;
+      if (n == 0) break;
+      if (ratio) {
+        if (mm_annotate_batch(ctxs[dr], aln, n, big.data(), n_big, 0, 0) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        ++submitted[dr];
+      } else {
+        for (size_t d = 0; d < N; ++d) { part_out[d] = stg[d].buf[submitted[d] % 3]; part_big[d] = stg[d].big.data(); }
+        if (mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg[0].big.size(), part_nbig.data(),
+                         part_max.data()) != MM_OK) { err << "mmannot-amd: cannot deal the batch out to the devices" << std::endl; return EXIT_FAILURE; }
+        const uint64_t qb = (mm_reader_qid_bound(rd) + N - 1) / N;
+        for (size_t d = 0; d < N; ++d) {
+          if (part_n[d] == 0) continue;
+          if (mm_annotate_batch(ctxs[d], part_out[d], part_n[d], part_big[d], part_nbig[d], qb, part_max[d] <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK) {
+            err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
+          }
+          ++submitted[d];
+        }
+      }
+      t_device += secs(t1, now());
+      cpt += n;
+      if (progress && n_threads == 1) err << "\t" << commas(cpt) << " lines read.\r" << std::flush;
+    }
+    err << "\t" << commas(mm_reader_n_reads(rd)) << " lines read, done." << std::endl;
+    for (mm_ctx *c : ctxs) if (mm_finalize(c) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    uint64_t st[MM_N_STATS];
+    size_t nr = 0;
+    if (mm_merge(ctxs.data(), (int) N, strategy, nullptr, nullptr, 0, &nr, st) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    std::vector<uint64_t> masks(nr ? nr : 1);
+    std::vector<double> sums(nr ? nr : 1);
+    if (nr && mm_merge(ctxs.data(), (int) N, strategy, masks.data(), sums.data(), nr, &nr, st) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    masks.resize(nr); sums.resize(nr);
+    report(fi, st, masks, sums, err, nullptr);
+    mm_reader_close(rd);
+    return 0;
+  };
   const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t) n_threads, n_inputs));
   int rc_all = 0;
-  if (n_workers == 1) {
+  if (shard_one_input) {
+    mm_options mopt = opt;
+    mopt.defer_ratio = strategy == MM_STRAT_RATIO ? 1 : 0;
+    std::vector<mm_ctx *> ctxs;
+    for (mm_index *ix : indices) {
+      mm_ctx *ctx = nullptr;
+      if (mm_ctx_create(&ctx, ix, &mopt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+      ctxs.push_back(ctx);
+    }
+    rc_all = process_file_multi(0, ctxs, std::cerr);
+    for (mm_ctx *c : ctxs) mm_ctx_destroy(c);
+  } else if (n_workers == 1) {
     Staging stg;
     RandomState rnd;
     mm_ctx *ctx = nullptr;

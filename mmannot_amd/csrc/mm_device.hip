@@ -62,7 +62,7 @@ extern "C" const char *mm_last_error(void) { return g_err.c_str(); }
 extern "C" const char *mm_version(void) { return MM_VERSION; }
 extern "C" void *mm_host_alloc(size_t bytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { g_err = "mm_host_alloc: hipHostMalloc failed"; return nullptr; }
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) { g_err = "mm_host_alloc: hipHostMalloc failed"; return nullptr; }
   return p;
 }
 extern "C" void mm_host_free(void *p) { if (p) (void) hipHostFree(p); }
@@ -76,7 +76,11 @@ extern "C" int mm_device_count(void) {
 #define LT_CAP 512u                // per-workgroup LDS table (with 1024 entries the merge kernel could not hold 8 waves per SIMD)
 #define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
-#define GT_NO_SLOT (GT_CAP - 1u)   // payload value "empty set" of a multi-hit record; gt_find_or_insert never returns this slot
+// A multi-hit record's element set travels to the merge kernels in 16 bits of its payload: e < 64 = the single element e (the
+// bulk: no table access on either side), GT_NO_SLOT = no element, anything else = the set's slot in the global table.
+// gt_find_or_insert therefore never hands out the slots below 64 or the last one.
+#define GT_NO_SLOT (GT_CAP - 1u)
+#define GT_FIRST_SLOT 64u
 #define MM_LDS_CHR 256               // chromosome tables up to this size are staged in LDS by k_probe
 // k_probe is a chain of dependent gathers (tuple -> slot line -> rest of the line), i.e. latency bound: it runs at the
 // hardware's maximum of 8 waves per SIMD (<= 64 VGPRs, < 20 KB LDS per 256 threads).  Measured on MI355X against the
@@ -97,10 +101,18 @@ __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits need
   while (b < 32 && (1ull << b) <= (unsigned long long) span) ++b;
   return b;
 }
-// Sort layout of this batch.  Multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys).  The key's
-// bits are split evenly over the passes an 8-bit layout would need - 21 bits are sorted as 3 x 7, not 8 + 8 + 5: fewer
-// digits per pass mean longer runs per digit inside a tile, i.e. longer contiguous segments in the scatter's writes.
-struct SortLayout { int passes; u32 width; };
+// Grouping layout of this batch.  Multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys).
+//   * "leaf" layout (the key range fits LEAF_BITS + LEAF_DIGIT_BITS bits - a 2^24-tuple batch of reads with ~10 hits each
+//     spans 21): ONE stable partition pass on the key's top bits, the "bucket" (key >> LEAF_BITS, up to 512 buckets); k_leaf
+//     then reduces each bucket's 4096 consecutive read names in LDS.  No full sort, no per-name gathers from HBM.
+//   * otherwise a full LSD sort, k_chunk_default behind it: the key's bits are split evenly over the passes an 8-bit layout
+//     would need - 24 bits are sorted as 3 x 8, 26 as 4 x 7 (fewer digits per pass mean longer runs per digit inside a tile,
+//     i.e. longer contiguous segments in the scatter's writes).
+#define LEAF_BITS 12
+#define LEAF_NAMES (1u << LEAF_BITS)
+#define LEAF_DIGIT_BITS 9
+#define RS_BINS (1u << LEAF_DIGIT_BITS)   // digit rows of the per-tile histograms (a pass uses the first 2^width of them)
+struct SortLayout { int passes; u32 width; u32 shift0; bool leaf; };
 __device__ __forceinline__ SortLayout batch_layout(const unsigned int *info, int fixed_bits) {
   int bits = fixed_bits;
   if (!bits) {
@@ -108,8 +120,10 @@ __device__ __forceinline__ SortLayout batch_layout(const unsigned int *info, int
     bits = qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
   }
   SortLayout L;
+  if (!fixed_bits && bits <= LEAF_BITS + LEAF_DIGIT_BITS) { L.passes = 1; L.width = LEAF_DIGIT_BITS; L.shift0 = LEAF_BITS; L.leaf = true; return L; }
   L.passes = (bits + 7) / 8;
   L.width = (u32) ((bits + L.passes - 1) / L.passes);
+  L.shift0 = 0; L.leaf = false;
   return L;
 }
 // passes this batch really runs: one (the compacting first pass) when the records are already grouped by name
@@ -117,8 +131,10 @@ __device__ __forceinline__ int batch_passes(const unsigned int *info, int fixed_
   if (!fixed_bits && !info[INFO_UNSORTED]) return 1;
   return batch_layout(info, fixed_bits).passes;
 }
+// is this batch reduced by k_leaf (else: by k_chunk_default, behind the full sort or - name-grouped input - the compaction)
+__device__ __forceinline__ bool batch_is_leaf(const unsigned int *info) { return info[INFO_UNSORTED] != 0 && batch_layout(info, 0).leaf; }
 // digit of key k in the pass the host launched with shift = 8 * pass
-__device__ __forceinline__ u32 batch_digit(u32 k, const SortLayout L, int shift) { return (k >> ((u32) (shift >> 3) * L.width)) & ((1u << L.width) - 1u); }
+__device__ __forceinline__ u32 batch_digit(u32 k, const SortLayout L, int shift) { return (k >> (L.shift0 + (u32) (shift >> 3) * L.width)) & ((1u << L.width) - 1u); }
 
 struct GlobalTable {
   u64 *key;      // 0 = empty (an element set is never empty)
@@ -238,12 +254,11 @@ __device__ __forceinline__ u32 slot_of_set(LdsTable &t, const struct GlobalTable
   return lds_cached_slot(t, g, m);
 }
 
-// returns slot or NO_KEY when full (error flag raised).  The last slot is never handed out: a multi-hit record's set travels
-// as a 16-bit slot number in its sort payload and GT_NO_SLOT there means "no element" (k_probe / k_chunk_default).
+// returns slot or NO_KEY when full (error flag raised); slots [GT_FIRST_SLOT, GT_NO_SLOT) only (see the payload encoding)
 __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
   u32 h = hash64(m) & (GT_CAP - 1);
   for (u32 p = 0; p < GT_CAP; ++p) {
-    if (h == GT_NO_SLOT) { h = 0; continue; }
+    if (h < GT_FIRST_SLOT || h == GT_NO_SLOT) { h = GT_FIRST_SLOT; continue; }
     u64 k = *(volatile u64 *) &g.key[h];
     if (k == 0) {
       k = atomicCAS(&g.key[h], 0ull, m);
@@ -254,6 +269,12 @@ __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
   }
   atomicCAS(g.err, 0u, (u32) ERR_TABLE_FULL);
   return NO_KEY;
+}
+
+// element set behind the 16-bit payload field of a multi-hit record
+__device__ __forceinline__ u64 payload_set(const GlobalTable &g, u32 slot) {
+  if (slot < GT_FIRST_SLOT) return 1ull << slot;
+  return slot == GT_NO_SLOT ? 0ull : g.key[slot];
 }
 
 __device__ __forceinline__ void gt_add(const GlobalTable &g, u64 m, u64 inc) {
@@ -533,6 +554,16 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
   return sel;
 }
 
+// scan() + getFirst() of one tuple: read strand from -s (strandF / strandR / strandU, mmannot.cpp:836-844), then the index
+template <int OVL>
+__device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, const uint2 *chrSlot, const u64 *sLine, const int4 a, u32 &walked) {
+  const int rec_strand = a.z & 1;
+  const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
+  // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
+  return (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
+                                    : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
+}
+
 // ----------------------------------------------------------------------------- k_probe
 // One lane per alignment, grid-stride over the batch.  Per alignment: scan+getFirst, the
 // three per-hit counters of addCount (mmannot.cpp:1666-1668), then either
@@ -575,13 +606,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     }
     const bool processed = valid && !(P.strategy == MM_STRAT_UNIQUE && nh != 1);  // mmannot.cpp:1773
     u64 mask = 0;
-    if (processed) {
-      const int rec_strand = a.z & 1;
-      const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
-      // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
-      mask = (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
-                                        : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
-    }
+    if (processed) mask = probe_tuple<OVL>(P, chrSlot, sLine, a, walked);
     const int np = __popcll(mask);
     const bool grouped = processed && grouped_strategy && nh > 1;
     cHits += __popcll(__ballot(processed));
@@ -602,16 +627,17 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
     //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
     if (counted && !ratio) count_set(T, G, mask);
-    if ((ratio && counted) || (grouped && mask != 0)) {
-      const u32 slot = slot_of_set(T, G, mask);
-      if (ratio) key = slot; else pay = slot & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
+    if (ratio && counted) key = slot_of_set(T, G, mask);
+    else if (grouped && mask != 0) {
+      if ((mask & (mask - 1)) == 0) pay = (u32) (__ffsll((long long) mask) - 1);   // one element: the payload names it
+      else pay = slot_of_set(T, G, mask) & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
     }
     if (valid) {
       if (gkey) {
         gkey[i] = key;                       // read again right away by the first sort pass: keep these cacheable
         gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
       }
-      if (hm && (P.keep || grouped)) st_stream(hm + i, processed ? mask : ~0ull);
+      if (hm && P.keep) st_stream(hm + i, processed ? mask : ~0ull);   // (parity / side channels only, see k_probe_sets)
     }
   }
   if (grouped_strategy && gkey) {
@@ -639,13 +665,34 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   lds_table_flush(T, G);
 }
 
+// The element set of a multi-hit record normally travels in 16 bits of its sort payload.  A batch holding an NH >= 65535 cannot
+// spare them (INFO_BIGNH: the payload is the record's index instead) - only then, which no real aligner output does, this kernel
+// runs the probe a second time and leaves every multi-hit record's set in hm[] for the merge kernels.  (Until round 2 k_probe
+// stored 8 bytes per multi-hit record for this case in every batch.)
+template <int OVL>
+__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_sets(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
+                                                                  size_t n, u64 *__restrict__ hm, const u32 *__restrict__ info, u32 *__restrict__ err) {
+  __shared__ u64 sLine[64];
+  __shared__ uint2 sChr[MM_LDS_CHR];
+  if (!info[INFO_BIGNH]) return;
+  if (threadIdx.x < 64) sLine[threadIdx.x] = P.lineMask[threadIdx.x];
+  for (u32 c = threadIdx.x; c < min(P.nchr, (u32) MM_LDS_CHR); c += blockDim.x) sChr[c] = P.chrSlot[c];
+  const uint2 *chrSlot = (P.nchr <= (u32) MM_LDS_CHR) ? sChr : P.chrSlot;
+  __syncthreads();
+  u32 walked = 0;
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+    const int4 a = ld_stream(aln + i);
+    if (tuple_nh((u32) a.z, i, big, nbig, err) > 1) hm[i] = probe_tuple<OVL>(P, chrSlot, sLine, a, walked);
+  }
+}
+
 // ----------------------------------------------------------------------------- grouping pipeline: tiles of (key, payload) pairs
 #define RS_THREADS 512
 #define RS_NW (RS_THREADS / 64)
 #define RS_ROUNDS 16
 #define RS_TILE (RS_THREADS * RS_ROUNDS)
 
-// ----------------------------------------------------------------------------- stable LSD radix sort (8-bit digits)
+// ----------------------------------------------------------------------------- stable radix passes (digits of up to 9 bits)
 // First pass (FIRST = true) reads the batch's records where k_probe left them: key gkey[i] (NO_KEY = not in the
 // grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
 // payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
@@ -654,18 +701,22 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
 // aggregation below costs 6 % of the sort there).  -y ratio sorts by table slot, where a handful of rows take most
 // records: then (skewed) the digit of the first pending lane is counted once for all the lanes that share it, twice,
 // before the rest use atomics - this removes the same-address serialisation SQ_WAIT_INST_LDS showed in these kernels.
+// SH = 0: h holds one u32 counter per digit; SH = 1: two 16-bit counters per u32 (digit d in half d & 1 of word d >> 1;
+// a wave adds at most 1024 per digit and tile, so a half never carries into its neighbour).
+template <int SH>
 __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewed) {
-  if (!skewed) { if (ok) atomicAdd(&h[d], 1u); return; }
+  const u32 idx = SH ? (d >> 1) : d, sh = SH ? ((d & 1u) << 4) : 0u;
+  if (!skewed) { if (ok) atomicAdd(&h[idx], 1u << sh); return; }
   const u32 lane = threadIdx.x & 63;
   u64 pend = __ballot(ok);
   for (int it = 0; it < 2 && pend; ++it) {
     const int l0 = __ffsll((long long) pend) - 1;
     const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
     const u64 same = __ballot(ok && d == d0) & pend;
-    if ((int) lane == l0) atomicAdd(&h[d0], (u32) __popcll(same));
+    if ((int) lane == l0) atomicAdd(&h[idx], (u32) __popcll(same) << sh);
     pend &= ~same;
   }
-  if ((pend >> lane) & 1ull) atomicAdd(&h[d], 1u);
+  if ((pend >> lane) & 1ull) atomicAdd(&h[idx], 1u << sh);
 }
 
 template <bool FIRST>
@@ -684,12 +735,13 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
   return true;
 }
 
-// Rows of `hist` (nblk entries each): 0..255 the digit counts per tile; for the first pass of the name sort also
-//   256 the tile's number of pairs, 257 / 258 its first / last key (NO_KEY: none) - see the order check below.
-#define RS_ROW_COUNT 256
-#define RS_ROW_FIRST 257
-#define RS_ROW_LAST 258
-#define RS_ROWS 259
+// Rows of `hist` (nblk entries each): 0..RS_BINS-1 the digit counts per tile (a pass writes the first 2^width of them); for the
+//   first pass of the name sort also RS_ROW_COUNT the tile's number of pairs, RS_ROW_FIRST / RS_ROW_LAST its first / last key
+//   (NO_KEY: none) - see the order check below.
+#define RS_ROW_COUNT RS_BINS
+#define RS_ROW_FIRST (RS_BINS + 1)
+#define RS_ROW_LAST (RS_BINS + 2)
+#define RS_ROWS (RS_BINS + 3)
 
 // Order check (first pass of the name sort only): an aligner writes the hits of one read one after the other, and read-name
 // ids are handed out in order of first appearance, so the qids of such a file are already non-decreasing and the "sort"
@@ -699,7 +751,7 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ info,
                                                         size_t n, int rebase, int shift, int fixed_bits, u32 *__restrict__ hist, u32 nblk) {
-  __shared__ u32 h[256];
+  __shared__ u32 h[RS_BINS];
   __shared__ u32 segF[RS_ROUNDS * RS_NW], segL[RS_ROUNDS * RS_NW];
   __shared__ u32 tileCnt, tileBad;
   if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
@@ -708,7 +760,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   // (the check stops at the first inversion: this wave's, or one another tile has already published)
   bool chk = order && ((volatile u32 *) info)[INFO_UNSORTED] == 0;
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x < 256) h[threadIdx.x] = 0;
+  h[threadIdx.x] = 0;                                    // (RS_THREADS == RS_BINS)
   if (threadIdx.x == 0) { tileCnt = 0; tileBad = chk ? 0u : 1u; }
   __syncthreads();
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
@@ -724,7 +776,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const u32 k = kk[r];
     const bool ok = (okm >> r) & 1u;
-    wave_hist_add(h, batch_digit(k, L, shift), ok, fixed_bits != 0);
+    wave_hist_add<0>(h, batch_digit(k, L, shift), ok, fixed_bits != 0);
     if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
       const u64 below = vm & ((1ull << lane) - 1ull);
@@ -736,7 +788,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   }
   if (chk && lane == 0) atomicAdd(&tileCnt, wcnt);
   __syncthreads();
-  if (threadIdx.x < 256) hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < (1u << L.width)) hist[(size_t) threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
   if (order && w == 0 && tileBad == 0) {   // the tile's segments in file order (segment = round * waves + wave), 64 at a time
     u32 carryL = NO_KEY, tfirst = NO_KEY, tlast = NO_KEY;
     bool sbad = false;
@@ -765,7 +817,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   if (order && threadIdx.x == 0 && tileBad && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
 }
 
-// One workgroup per digit: exclusive scan of its row of per-tile counts.  The workgroup that finishes last then turns the
+// One workgroup per digit row: exclusive scan of its row of per-tile counts.  The workgroup that finishes last then turns the
 // row totals into the digits' global bases (and, for the first pass of the name sort, finishes the order check between
 // tiles and publishes the number of pairs) - one launch instead of two on a path made of short kernels.
 __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal, u32 *__restrict__ done,
@@ -778,8 +830,10 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // digit rows this pass did not write (its digits are narrower than RS_BINS) total zero; every other row is scanned:
   // every thread owns 16 consecutive tiles: all its loads are in flight together, then local scan -> wave -> workgroup
-  for (u32 base = 0; base < nblk; base += 256 * 16) {
+  const bool unused = blockIdx.x < RS_BINS && blockIdx.x >= (1u << batch_layout(info, fixed_bits).width);   // block-uniform
+  for (u32 base = 0; base < nblk && !unused; base += 256 * 16) {
     const u32 i0 = base + threadIdx.x * 16;
     u32 v[16];
 #pragma unroll
@@ -836,8 +890,9 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
     }
     if (bad) atomicOr(&info[INFO_UNSORTED], 1u);
   }
-  {  // exclusive scan of the 256 row totals
-    const u32 v = ((volatile u32 *) rowTotal)[threadIdx.x];
+  {  // exclusive scan of the RS_BINS row totals, two per thread
+    const u32 v0 = ((volatile u32 *) rowTotal)[2 * threadIdx.x], v1 = ((volatile u32 *) rowTotal)[2 * threadIdx.x + 1];
+    const u32 v = v0 + v1;
     u32 x = v;
     for (int off = 1; off < 64; off <<= 1) {
       const u32 y = __shfl_up(x, off);
@@ -848,7 +903,8 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
     __syncthreads();
     u32 woff = 0;
     for (u32 k = 0; k < w; ++k) woff += wsum[k];
-    rowTotal[threadIdx.x] = woff + x - v;
+    rowTotal[2 * threadIdx.x] = woff + x - v;
+    rowTotal[2 * threadIdx.x + 1] = woff + x - v + v0;
     if (threadIdx.x == 255) {
       const u32 acc = woff + x;
       if (shift == 0) info[INFO_M] = acc;   // the first pass compacts: this is the number of pairs in the pipeline
@@ -857,25 +913,26 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
   }
 }
 
-// One pass of the stable LSD sort for one tile of RS_TILE pairs (8192: 512 threads, 64 KB of LDS, two workgroups per CU;
+// One stable pass for one tile of RS_TILE pairs (8192: 512 threads, 74 KB of LDS, two workgroups per CU;
 // measured against 4096-pair tiles of 256 threads: sort -3 %, ordered compaction -7 % - longer digit runs, half the tiles).
 //   A. every wave owns a contiguous eighth of the tile, keeps its 16x64 pairs in registers and counts digits
-//      per wave in LDS;
+//      per wave in LDS (16-bit counters, two to a word);
 //   B. per-digit exclusive offsets (tile-local and global) from those counts;
-//   C. each wave ranks its pairs sub-round by sub-round (8 ballots per pair give the lanes holding the same
+//   C. each wave ranks its pairs sub-round by sub-round (one ballot per digit bit gives the lanes holding the same
 //      digit) against its private running offsets - no workgroup barrier inside the loop - and drops the pairs
 //      at their tile-local sorted position in LDS;
 //   D. the sorted tile is copied out: consecutive lanes write consecutive addresses inside each digit run, so
-//      the scatter reaches memory as 64-B-and-longer segments instead of isolated 4-B stores.
+//      the scatter reaches memory as 64-B-and-longer segments instead of isolated 4-B stores.  The partition pass of the
+//      "leaf" layout writes each pair as one 8-byte word (key << 32 | payload): k_leaf streams those.
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
                                                            u32 *__restrict__ vout, const u32 *__restrict__ info, size_t n, int rebase, int shift,
                                                            int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
   __shared__ u32 lkey[RS_TILE];
   __shared__ u32 lval[RS_TILE];
-  __shared__ u32 cntw[RS_NW][256];   // A: digit counts per wave; C: running tile-local offset per wave
-  __shared__ u32 goff[256];      // global position of digit d's first pair of this tile, minus its tile-local offset
-  __shared__ u32 wsum[4];
+  __shared__ __attribute__((aligned(16))) unsigned short cntw[RS_NW][RS_BINS];   // A: digit counts per wave; C: running tile-local offset per wave (< 8192)
+  __shared__ u32 goff[RS_BINS];      // global position of digit d's first pair of this tile, minus its tile-local offset
+  __shared__ u32 wsum[RS_NW];
   __shared__ u32 tcountS;
   if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
   const SortLayout L = batch_layout(info, fixed_bits);
@@ -884,9 +941,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   if (lo >= lim) return;
   // name-grouped input (see k_rs_hist): one "digit" for everything, i.e. a stable compaction in file order
   const bool presorted = FIRST && rebase && !info[INFO_UNSORTED];
-  const u32 dmask = presorted ? 0u : 255u;   // (presorted: every pair in "digit" 0)
+  const u32 dmask = presorted ? 0u : (RS_BINS - 1u);   // (presorted: every pair in "digit" 0)
+  const bool pairs64 = FIRST && rebase && !presorted && L.leaf;   // output format of the leaf layout's partition pass
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
-  if (t < 256) for (u32 q = 0; q < RS_NW; ++q) cntw[q][t] = 0;
+  for (u32 q = 0; q < RS_NW; ++q) cntw[q][t] = 0;
   __syncthreads();
   u32 kreg[RS_ROUNDS], vreg[RS_ROUNDS];
   u32 vmask = 0;                     // which of this lane's 16 pairs exist (the first pass filters on the fly)
@@ -899,8 +957,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     if (ok) vmask |= 1u << r;
     if (presorted) {   // (wave-uniform) all pairs count for digit 0: one add per wave instead of 64 colliding atomics
       const u32 c = (u32) __popcll(__ballot(ok));
-      if (lane == 0) cntw[w][0] += c;
-    } else wave_hist_add(cntw[w], batch_digit(kreg[r], L, shift), ok, fixed_bits != 0);
+      if (lane == 0) cntw[w][0] = (unsigned short) (cntw[w][0] + c);
+    } else wave_hist_add<1>((u32 *) cntw[w], batch_digit(kreg[r], L, shift), ok, fixed_bits != 0);
   }
   __syncthreads();
   if (presorted) {   // plain ordered compaction: the pairs go straight from the registers to their place, in file order
@@ -916,26 +974,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     }
     return;
   }
-  {  // B: thread t owns digit t (the first 256 threads)
-    u32 tot = 0, x = 0;
-    if (t < 256) {
-      for (u32 q = 0; q < RS_NW; ++q) tot += cntw[q][t];
-      x = tot;
-      for (int off = 1; off < 64; off <<= 1) {
-        const u32 y = __shfl_up(x, off);
-        if ((int) lane >= off) x += y;
-      }
-      if (lane == 63) wsum[w] = x;
+  {  // B: thread t owns digit t
+    u32 tot = 0;
+    for (u32 q = 0; q < RS_NW; ++q) tot += cntw[q][t];
+    u32 x = tot;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if ((int) lane >= off) x += y;
     }
+    if (lane == 63) wsum[w] = x;
     __syncthreads();
-    if (t < 256) {
-      u32 loff = x - tot;
-      for (u32 q = 0; q < w; ++q) loff += wsum[q];
-      if (t == 255) tcountS = loff + tot;                  // number of pairs this tile holds
-      goff[t] = base[t] + hist[(size_t) t * nblk + blockIdx.x] - loff;
-      u32 run = loff;
-      for (u32 q = 0; q < RS_NW; ++q) { const u32 c = cntw[q][t]; cntw[q][t] = run; run += c; }
-    }
+    u32 loff = x - tot;
+    for (u32 q = 0; q < w; ++q) loff += wsum[q];
+    if (t == RS_BINS - 1) tcountS = loff + tot;                  // number of pairs this tile holds
+    goff[t] = base[t] + (t < (1u << L.width) ? hist[(size_t) t * nblk + blockIdx.x] : 0u) - loff;
+    u32 run = loff;
+    for (u32 q = 0; q < RS_NW; ++q) { const u32 c = cntw[q][t]; cntw[q][t] = (unsigned short) run; run += c; }
   }
   __syncthreads();
 #pragma unroll
@@ -944,18 +998,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     const u32 d = batch_digit(kreg[r], L, shift) & dmask;
     u64 peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < LEAF_DIGIT_BITS; ++b) {
       const u64 bb = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bb : ~bb;
     }
     const u32 rank = (u32) __popcll(peers & ((1ull << lane) - 1));
     u32 pos = 0;
-    if (valid) pos = cntw[w][d] + rank;
-    if (valid && rank == 0) cntw[w][d] = pos + (u32) __popcll(peers);
+    if (valid) pos = (u32) cntw[w][d] + rank;
+    if (valid && rank == 0) cntw[w][d] = (unsigned short) (pos + (u32) __popcll(peers));
     if (valid) { lkey[pos] = kreg[r]; lval[pos] = vreg[r]; }
   }
   __syncthreads();
   const u32 tcount = tcountS;
+  if (pairs64) {
+    u64 *__restrict__ rout = (u64 *) kout;      // (kout and vout are the two halves of one allocation)
+    for (u32 i = t; i < tcount; i += RS_THREADS) {
+      const u32 k = lkey[i];
+      rout[goff[batch_digit(k, L, shift)] + i] = ((u64) k << 32) | lval[i];
+    }
+    return;
+  }
   for (u32 i = t; i < tcount; i += RS_THREADS) {  // D
     const u32 k = lkey[i];
     const u32 g = goff[batch_digit(k, L, shift) & dmask] + i;
@@ -980,6 +1042,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ u32 sOpened, sRescued;
   __shared__ u32 sKey[256 + 64], sNh[256 + 64];   // this round's records and the 64 behind them
   __shared__ u64 sM[256 + 64];
+  if (batch_is_leaf(info)) return;                       // this batch is k_leaf's
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
   if (info[INFO_M] != 0 && (u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
   lds_table_init(T);
@@ -996,7 +1059,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // payload of a record of the sorted stream -> (element set, NH)
   auto decode = [&](u32 pv, u64 &m, u32 &nhv) __attribute__((always_inline)) {
     if (by_index) { m = hm[pv]; nhv = tuple_nh((u32) aln[pv].z, pv, big, nbig, G.err); }
-    else { const u32 slot = pv & 0xFFFFu; m = (slot == GT_NO_SLOT) ? 0ull : G.key[slot]; nhv = pv >> 16; }
+    else { m = payload_set(G, pv & 0xFFFFu); nhv = pv >> 16; }
   };
   auto fetch = [&](size_t k, u64 &m, u32 &nhv) __attribute__((always_inline)) { decode(svals[k], m, nhv); };
   auto close_group = [&](u64 U) __attribute__((always_inline)) {
@@ -1138,6 +1201,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (rescued) atomicAdd(&sRescued, rescued);
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (sOpened) atomicAdd(&stats[MM_STAT_READS], (u64) sOpened);   // ++nReads per new group, mmannot.cpp:1675
+    if (sRescued) atomicAdd(&stats[MM_STAT_RESCUED], (u64) sRescued);
+  }
+  lds_table_flush(T, G);
+}
+
+// ----------------------------------------------------------------------------- k_leaf: multi-hit countdown / union per bucket, in LDS
+// "Leaf" layout (see batch_layout): the partition pass has brought the batch's multi-hit records together by bucket = 4096
+// consecutive read names, file order kept inside a bucket.  One workgroup takes a bucket:
+//   A. streams its records once (8 B each) and reduces them per name in LDS - union of the element sets, record count,
+//      OR and AND of the NH values (all NH of a name equal <=> OR == AND);
+//   B. per name, reads the state carried from earlier batches (remaining, union) - consecutive names, so coalesced - and
+//      applies the countdown of addCount (mmannot.cpp:1669-1701) in closed form where the order of the records cannot
+//      matter: they all fall into the pending group, or they open exactly one new group;
+//   C. names where the order does matter (a group closes inside the run: over-complete names such as both mates under one
+//      name, mixed NH) are replayed in file order: a second sweep over the bucket, workgroup-chunk by chunk, wave by wave,
+//      lanes of one wave that hold the same name one after the other.  Every other lane skips it.
+// Exact for every input; the common case costs one streaming read of the records and no per-name gather from HBM.
+#define LEAF_THREADS 1024
+#define LEAF_ILL 0xFFFFFFFFu   // sOA value marking an order-dependent name (no OR/AND pair of 16-bit NH values looks like this)
+__global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_leaf(
+    const u64 *__restrict__ recs, const u32 *__restrict__ info, const u32 *__restrict__ base, const int4 *__restrict__ aln,
+    const uint2 *__restrict__ big, u32 nbig, const u64 *__restrict__ hm, u32 *__restrict__ grpRem, u64 *__restrict__ grpU, u64 qcap,
+    GlobalTable G, u64 *__restrict__ stats) {
+  __shared__ LdsTable T;
+  __shared__ u64 sU[LEAF_NAMES];     // A: union of the name's sets in this batch; C: the name's union so far
+  __shared__ u32 sCnt[LEAF_NAMES];   // A: records of the name in this batch;      C: the name's remaining count
+  __shared__ u32 sOA[LEAF_NAMES];    // A: AND << 16 | OR of the name's NH values;  C: LEAF_ILL marks the names being replayed
+  __shared__ u32 sOpened, sRescued, sIll;
+  if (!batch_is_leaf(info)) return;                      // this batch is k_chunk_default's
+  // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
+  if ((u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
+  const u32 M = info[INFO_M];
+  const u32 qmin = ~info[INFO_QINV];
+  const u32 nbk = ((info[INFO_QMAX] - qmin) >> LEAF_BITS) + 1u;      // <= RS_BINS by the layout's definition
+  const bool by_index = info[INFO_BIGNH] != 0;
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+  lds_table_init(T);
+  if (t == 0) { sOpened = 0; sRescued = 0; }
+  u32 opened = 0, rescued = 0;
+  auto decode = [&](u32 pv, u64 &m, u32 &nhv) __attribute__((always_inline)) {
+    if (by_index) { m = hm[pv]; nhv = tuple_nh((u32) aln[pv].z, pv, big, nbig, G.err); }
+    else { m = payload_set(G, pv & 0xFFFFu); nhv = pv >> 16; }
+  };
+  auto close_group = [&](u64 U) __attribute__((always_inline)) {
+    if (U) {
+      count_set(T, G, U);
+      if ((U & (U - 1)) == 0) ++rescued;
+    }
+  };
+  for (u32 b = blockIdx.x; b < nbk; b += gridDim.x) {    // (workgroup-uniform)
+    const u32 lo = base[b], hi = (b + 1 < RS_BINS) ? base[b + 1] : M;
+    __syncthreads();                                     // the previous bucket's LDS state is no longer read
+    if (hi <= lo) continue;
+    for (u32 i = t; i < LEAF_NAMES; i += LEAF_THREADS) { sU[i] = 0; sCnt[i] = 0; sOA[i] = 0xFFFF0000u; }
+    if (t == 0) sIll = 0;
+    __syncthreads();
+    // ---- A: one streaming pass, four records per lane in flight
+    for (u64 i0 = (u64) lo + t; i0 < hi; i0 += 4 * LEAF_THREADS) {
+      u64 r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u64 i = i0 + (u64) k * LEAF_THREADS; r[k] = (i < hi) ? recs[i] : ~0ull; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + (u64) k * LEAF_THREADS < hi) {
+          const u32 loc = (u32) (r[k] >> 32) & (LEAF_NAMES - 1u);
+          atomicAdd(&sCnt[loc], 1u);
+          if (!by_index) {                                // (by index: every name is replayed, the reduction is not used)
+            u64 m; u32 nhv;
+            decode((u32) r[k], m, nhv);
+            if (m) atomicOr(&sU[loc], m);
+            atomicOr(&sOA[loc], nhv);                     // OR in the low half (NH < 65535 here) ...
+            atomicAnd(&sOA[loc], (nhv << 16) | 0xFFFFu);  // ... AND in the high half
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B: closed form per name
+    const u32 q0 = qmin + (b << LEAF_BITS);
+    for (u32 nm = t; nm < LEAF_NAMES; nm += LEAF_THREADS) {
+      const u32 c = sCnt[nm];
+      if (c == 0) { sOA[nm] = 0; continue; }
+      const u32 q = q0 + nm;                              // (a name with records has key <= qmax, so q < qcap)
+      u32 rem = grpRem[q];
+      u64 U = grpU[q];
+      const u64 tU = sU[nm];
+      const u32 oa = sOA[nm], nor = oa & 0xFFFFu, nand = oa >> 16;
+      bool ill = false;
+      if (by_index) ill = true;
+      else if (rem > 0 && c <= rem) {
+        // all records fall into the pending group of this name (their own NH is irrelevant, mmannot.cpp:1681-1684)
+        U |= tU; rem -= c;
+        if (rem == 0) { close_group(U); U = 0; }
+      } else if (rem == 0 && nor == nand && c <= nor) {
+        // one new group, opened by the first record: remaining = NH-1 (mmannot.cpp:1673), order of the others is irrelevant
+        ++opened; U = tU; rem = nor - c;
+        if (rem == 0) { close_group(U); U = 0; }
+      } else ill = true;
+      if (ill) { sU[nm] = U; sCnt[nm] = rem; sOA[nm] = LEAF_ILL; atomicAdd(&sIll, 1u); }   // C starts from the carried state
+      else { grpRem[q] = rem; grpU[q] = U; sOA[nm] = 0; }
+    }
+    __syncthreads();
+    if (sIll == 0) continue;                              // (workgroup-uniform)
+    // ---- C: order-dependent names, replayed in file order
+    for (u64 cb = lo; cb < hi; cb += LEAF_THREADS) {
+      const u64 i = cb + t;
+      u32 loc = 0, nhv = 0;
+      u64 m = 0;
+      bool mine = false;
+      if (i < hi) {
+        const u64 r = recs[i];
+        loc = (u32) (r >> 32) & (LEAF_NAMES - 1u);
+        mine = ((volatile u32 *) sOA)[loc] == LEAF_ILL;
+        if (mine) decode((u32) r, m, nhv);
+      }
+      if (!__syncthreads_or(mine ? 1 : 0)) continue;      // nothing to replay in these 1024 records
+      // lanes of this wave holding the same name, in lane (= file) order
+      u64 peers = __ballot(mine);
+#pragma unroll
+      for (int bit = 0; bit < LEAF_BITS; ++bit) {
+        const u64 bb = __ballot((loc >> bit) & 1u);
+        peers &= ((loc >> bit) & 1u) ? bb : ~bb;
+      }
+      const u32 rank = (u32) __popcll(peers & ((1ull << lane) - 1ull));
+      for (u32 ww = 0; ww < LEAF_THREADS / 64; ++ww) {    // the workgroup's waves one after the other
+        if (w == ww) {
+          for (u32 rr = 0; __ballot(mine && rank >= rr); ++rr) {
+            if (mine && rank == rr) {                     // (LDS operations of one wave execute in program order)
+              u32 rem = ((volatile u32 *) sCnt)[loc];
+              u64 U = ((volatile u64 *) sU)[loc];
+              if (rem == 0) { rem = nhv - 1; U = m; ++opened; }          // mmannot.cpp:1672-1677
+              else {                                                     // mmannot.cpp:1678-1701
+                --rem; U |= m;
+                if (rem == 0) { close_group(U); U = 0; }
+              }
+              ((volatile u32 *) sCnt)[loc] = rem;
+              ((volatile u64 *) sU)[loc] = U;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (u32 nm = t; nm < LEAF_NAMES; nm += LEAF_THREADS)
+      if (sOA[nm] == LEAF_ILL) { grpRem[q0 + nm] = sCnt[nm]; grpU[q0 + nm] = sU[nm]; }
+  }
+  if (opened) atomicAdd(&sOpened, opened);
+  if (rescued) atomicAdd(&sRescued, rescued);
+  __syncthreads();
+  if (t == 0) {
     if (sOpened) atomicAdd(&stats[MM_STAT_READS], (u64) sOpened);   // ++nReads per new group, mmannot.cpp:1675
     if (sRescued) atomicAdd(&stats[MM_STAT_RESCUED], (u64) sRescued);
   }
@@ -1828,7 +2042,7 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 static void ctx_free_batch(mm_ctx *c) {
   for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); c->d_alnBuf[b] = nullptr; c->consumed_valid[b] = false; c->copied_valid[b] = false; }
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
-  (void) hipFree(c->d_kA); (void) hipFree(c->d_vA); (void) hipFree(c->d_kB); (void) hipFree(c->d_vB);
+  (void) hipFree(c->d_kA); (void) hipFree(c->d_kB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
   c->d_tileTot = nullptr; c->d_tileK = nullptr;
   c->d_aln = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
@@ -1904,8 +2118,9 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     ctx_free_batch(c);
     const size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
     HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_gpay, cap * 4));
-    HIPCHK(hipMalloc((void **) &c->d_kA, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vA, cap * 4));
-    HIPCHK(hipMalloc((void **) &c->d_kB, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_vB, cap * 4));
+    // (keys and payloads of one buffer are the two halves of one allocation: the leaf layout's partition pass writes 8-byte pairs there)
+    HIPCHK(hipMalloc((void **) &c->d_kA, cap * 8)); c->d_vA = c->d_kA + cap;
+    HIPCHK(hipMalloc((void **) &c->d_kB, cap * 8)); c->d_vB = c->d_kB + cap;
     HIPCHK(hipMalloc((void **) &c->d_hist, (size_t) RS_ROWS * nblk * 4));
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
@@ -1966,14 +2181,14 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
   hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
   // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
-  hipLaunchKernelGGL(k_rs_scan, dim3(rebase ? RS_ROW_COUNT + 1 : 256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
+  hipLaunchKernelGGL(k_rs_scan, dim3(rebase ? RS_ROW_COUNT + 1 : RS_BINS), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
                      c->d_M, 0, fixed_bits, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
                      fixed_bits, c->d_hist, c->d_rowTot, nblk);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int shift = 8; shift < max_bits; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
-    hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
+    hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
                        fixed_bits, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk);
@@ -2088,6 +2303,18 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
   }
   }
+  if (dflt && need_groups && !c->opt.keep_hit_masks) {   // (returns at once unless the batch holds an NH >= 65535)
+    switch (c->opt.overlap_mode) {
+      case MM_OVL_INCLUSION:
+        hipLaunchKernelGGL(k_probe_sets<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, n, hm, c->d_M, c->G.err);
+        break;
+      case MM_OVL_PC:
+        hipLaunchKernelGGL(k_probe_sets<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, n, hm, c->d_M, c->G.err);
+        break;
+      default:
+        hipLaunchKernelGGL(k_probe_sets<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, n, hm, c->d_M, c->G.err);
+    }
+  }
   HIPCHK(hipGetLastError());
   c->last_n = n;
   c->last_aln = d_aln;
@@ -2098,10 +2325,14 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
-    if (dflt)
+    if (dflt) {
+      // exactly one of the two does the work (device-side decision, batch_is_leaf): k_leaf behind the partition pass of the leaf
+      // layout, k_chunk_default behind the full sort or - name-grouped input - the plain compaction
+      hipLaunchKernelGGL(k_leaf, dim3(RS_BINS), dim3(LEAF_THREADS), 0, c->stream, (const u64 *) c->d_kB, c->d_M, c->d_rowTot, d_aln, d_big, (u32) n_big, hm,
+                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_aln, d_big, (u32) n_big, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
-    else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
+    } else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
       mm_ctx::Run r;
       r.n = n;
       HIPCHK(hipMalloc((void **) &r.k, n * 4)); HIPCHK(hipMalloc((void **) &r.v, n * 4)); HIPCHK(hipMalloc((void **) &r.info, INFO_WORDS * 4));
@@ -2167,18 +2398,26 @@ extern "C" int mm_set_row_sums(mm_ctx *c, const uint64_t *masks, const double *s
   return check_table(c);
 }
 
-extern "C" int mm_ratio_resolve(mm_ctx *c) {
+extern "C" size_t mm_ratio_pending(const mm_ctx *c) { return c ? c->runs.size() : 0; }
+
+extern "C" int mm_ratio_resolve_n(mm_ctx *c, size_t max_runs) {
   if (!c) return fail(MM_ERR_ARG, "mm_ratio_resolve: null context");
   HIPCHK(hipSetDevice(c->ix->device));
+  size_t done = 0;
   for (auto &r : c->runs) {
+    if (done == max_runs) break;
     PhaseTimer t(c, MM_PHASE_MERGE);
     int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n);
     if (rc) return rc;
+    ++done;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  free_runs(c);
+  for (size_t k = 0; k < done; ++k) { (void) hipFree(c->runs[k].k); (void) hipFree(c->runs[k].v); (void) hipFree(c->runs[k].info); }
+  c->runs.erase(c->runs.begin(), c->runs.begin() + (long) done);
   return check_table(c);
 }
+
+extern "C" int mm_ratio_resolve(mm_ctx *c) { return mm_ratio_resolve_n(c, (size_t) -1); }
 
 extern "C" int mm_set_profiling(mm_ctx *c, int on) {
   if (!c) return fail(MM_ERR_ARG, "mm_set_profiling: null context");

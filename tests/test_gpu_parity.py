@@ -391,3 +391,25 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
             assert (r["hit"] == ref.hit_mask).all()
             assert r["stats"] == ref.stats, (order_kind, batches)
             assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order_kind, batches)
+
+
+@pytest.mark.parametrize("stride,shuffle", [(1, True), (700, True), (700, False), (70000, True)])
+def test_every_grouping_layout(gpu_lib, oracle, stride, shuffle):
+    """The multi-hit merge picks its path per batch on the device: name-grouped input -> compaction + k_chunk_default; a key range
+    of at most 21 bits -> one partition pass + k_leaf (LDS reduction per bucket of 4096 names, file-order replay of the names
+    whose record order matters); wider ranges -> full LSD sort + k_chunk_default.  Same reads, read-name ids spread out by
+    `stride` to force each layout (3, 4 and - stride 70000 - 31 key bits), malformed groups included: always the oracle's answer,
+    whatever the batch split."""
+    mm = gpu_lib
+    rng = np.random.default_rng(2024)
+    desc = sr.random_config(rng, n_lines=6, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=2500, maxpos=120000)
+    reads = sr.random_reads(rng, ix, n=30000, nchr=3, maxpos=120000, nh_max=9, shuffle=shuffle)
+    reads = dict(reads, qid=reads["qid"] * stride)
+    ref = oracle.run(desc, ix, reads, overlap=0.3, strandedness="R", strategy="default", want_hit_mask=True)
+    cfg = to_cfg(mm, desc)
+    for batches in (1, 4):
+        r = run_gpu(mm, cfg, ix, reads, overlap=0.3, strandedness="R", strategy="default", batches=batches)
+        assert (r["hit"] == ref.hit_mask).all()
+        assert r["stats"] == ref.stats, (stride, shuffle, batches)
+        assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (stride, shuffle, batches)
