@@ -132,6 +132,11 @@ def main():
     qb = int(nb * B * groups_per_tuple) + nh_max + 2   # exclusive bound of the read-name ids of the whole stream (a larger bound is allowed)
     total_tuples = world * nb * B
 
+    def qlo(step):   # smallest read-name id a multi-hit tuple of this batch can have (the decoder of a real input knows it too)
+        if nh_max <= 1:
+            return 0
+        return (step * B // (nh_max * (nh_max + 1) // 2)) * nh_max
+
     def run_leg(from_host: bool):
         """W warm-up steps, then K timed steps + end-of-file flush + cross-rank merge, bracketed by barrier + synchronize.
         Returns (elapsed seconds = max over ranks, phases of the timed region, masks, sums, stats)."""
@@ -143,9 +148,9 @@ def main():
 
         def step(s):
             if host is not None:
-                ctr.add_batch_host(host[s].data_ptr(), B, qb, single_hit=single)
+                ctr.add_batch_host(host[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
             else:
-                ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
+                ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
 
         for s in range(args.warmup):
             step(s)
@@ -200,11 +205,11 @@ def main():
     else:
         ctr.clear()
         for s in range(args.warmup):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
+            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         ctr.set_profiling(1)
         for s in range(args.warmup, args.warmup + n_phase):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single)
+            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         phases_all = ctr.phase_ms()
         ctr.set_profiling(0)

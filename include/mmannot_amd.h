@@ -141,11 +141,15 @@ int mm_reset(mm_ctx *ctx);
  *        before the call returns.
  *   qid_bound: exclusive upper bound of every qid seen so far including this batch (sizes the
  *        per-read-name state of -y default; ignored by the other strategies).
+ *   qid_lo: hint, 0 = none: no tuple of this batch with NH > 1 has a qid below it (the decoder knows; MM_ERR_ARG at the next
+ *        mm_sync when one does).  The span qid_bound - qid_lo tells the host how many grouping passes the batch can need, so
+ *        none is launched in vain.
  *   flags: MM_BATCH_ON_DEVICE; MM_BATCH_SINGLE_HIT = the caller promises that every tuple has NH <= 1 (checked on the
  *        device, MM_ERR_ARG at the next mm_sync otherwise): the multi-hit pipeline is not launched at all.
  * Batches must be submitted in file order (the multi-hit countdown is order dependent, mmannot.cpp:1669-1701). */
 enum { MM_BATCH_ON_DEVICE = 1, MM_BATCH_SINGLE_HIT = 2 };
-int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_bound, uint32_t flags);
+int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo, uint64_t qid_bound,
+                      uint32_t flags);
 /* pinned (page-locked) host memory for tuple batches: hipHostMalloc / hipHostFree */
 void *mm_host_alloc(size_t bytes);
 void mm_host_free(void *p);
@@ -184,7 +188,7 @@ size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet
  * spread whole files).  One context per device, each on its own copy of the index.
  * mm_partition (host): deals the tuples of one decoded batch out by qid mod n_parts, file order kept inside each part, read names
  * renumbered qid / n_parts (dense per part; the caller passes ceil(qid_bound / n_parts) on).  out[p] needs room for n tuples,
- * out_big[p] for big_cap entries; out_max_nh[p] (may be NULL) = the part's largest NH.  Every hit of a name lands in one part,
+ * out_big[p] for big_cap entries; out_max_nh[p] / out_qid_lo[p] (may be NULL) = the part's largest NH / smallest renumbered qid with NH > 1.  Every hit of a name lands in one part,
  * which is what the multi-hit countdown of -y default needs (mmannot.cpp:1669-1701); -y unique may use it too.
  * -y ratio instead sends whole batches round-robin (batch j to context j mod n, contexts created with defer_ratio): its per-row
  * double sums are file-order dependent (mmannot.cpp:1730).
@@ -193,7 +197,7 @@ size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet
  * ended with.  masks NULL: only *n_rows and stats.  (Ranks that are separate processes merge with an all_gather of the keys and
  * an all_reduce of the dense count vector over RCCL instead: mmannot_amd/dist.py.) */
 int mm_partition(const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, int n_parts, mm_aln *const *out, size_t *out_n,
-                 mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh);
+                 mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh, uint64_t *out_qid_lo);
 int mm_merge(mm_ctx *const *ctxs, int n_ctx, int strategy, uint64_t *masks, double *sums, size_t cap, size_t *n_rows,
              uint64_t stats[MM_N_STATS]);
 
@@ -246,6 +250,8 @@ const char *mm_reader_error(const mm_reader *r);
  * to big[] (capacity big_cap >= 1; the batch ends early when it is full), *n_big of them.  *max_nh (may be NULL) receives the
  * largest NH of the batch: <= 1 allows MM_BATCH_SINGLE_HIT. */
 int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n, mm_nh_big *big, size_t big_cap, size_t *n_big, uint32_t *max_nh);
+/* smallest qid among the tuples with NH > 1 of the batch mm_reader_next delivered last (mm_annotate_batch's qid_lo; the qid bound when there is none) */
+uint64_t mm_reader_qid_lo(const mm_reader *r);
 uint64_t mm_reader_qid_bound(const mm_reader *r);
 uint64_t mm_reader_n_reads(const mm_reader *r);       /* the "lines read" counter of Counter::read, mmannot.cpp:1782 */
 const char *mm_reader_name(const mm_reader *r, uint32_t qid);

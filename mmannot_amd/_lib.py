@@ -61,7 +61,7 @@ SYMBOLS = {
     "mm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Options), C.c_void_p]),
     "mm_ctx_destroy": (None, [C.c_void_p]),
     "mm_reset": (C.c_int, [C.c_void_p]),
-    "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32]),
+    "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32]),
     "mm_host_alloc": (C.c_void_p, [C.c_size_t]),
     "mm_host_free": (None, [C.c_void_p]),
     "mm_sync": (C.c_int, [C.c_void_p]),
@@ -76,7 +76,7 @@ SYMBOLS = {
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mm_ratio_pending": (C.c_size_t, [C.c_void_p]),
     "mm_partition": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
-                               C.c_void_p]),
+                               C.c_void_p, C.c_void_p]),
     "mm_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -101,6 +101,7 @@ SYMBOLS = {
     "mm_reader_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_uint32)]),
     "mm_reader_qid_bound": (C.c_uint64, [C.c_void_p]),
+    "mm_reader_qid_lo": (C.c_uint64, [C.c_void_p]),
     "mm_reader_n_reads": (C.c_uint64, [C.c_void_p]),
     "mm_reader_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mm_reader_take_log": (C.c_char_p, [C.c_void_p]),

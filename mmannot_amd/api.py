@@ -189,7 +189,7 @@ class Counter:
     def clear(self):  # Counter::clear mmannot.cpp:1742-1747
         check(lib().mm_reset(self._h))
 
-    def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int, single_hit: Optional[bool] = None):
+    def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int, single_hit: Optional[bool] = None, qid_lo: int = 0):
         """Host tuples (mm_aln structured array) -> one batch of the loop of Counter::read (mmannot.cpp:1772-1781).
         nh given: the NH of every tuple (packed into a copy of the tuples, values beyond the field into the side list);
         nh None: the tuples' own NH fields count."""
@@ -204,18 +204,19 @@ class Counter:
         if single_hit is None:
             single_hit = len(aln) > 0 and int(((aln["tsn"] >> np.uint32(1)) & np.uint32(NH_ESCAPE)).max()) <= 1
         self._keep.append(aln)
-        check(lib().mm_annotate_batch(self._h, aln.ctypes.data, len(aln), big.ctypes.data if len(big) else None, len(big), int(qid_bound),
+        check(lib().mm_annotate_batch(self._h, aln.ctypes.data, len(aln), big.ctypes.data if len(big) else None, len(big), int(qid_lo), int(qid_bound),
                                       _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
 
-    def add_batch_device(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False, big: Optional[np.ndarray] = None):
+    def add_batch_device(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False, big: Optional[np.ndarray] = None, qid_lo: int = 0):
         """Tuples already resident in HBM (e.g. a torch tensor: pass .data_ptr())."""
         flags = _lib.MM_BATCH_ON_DEVICE | (_lib.MM_BATCH_SINGLE_HIT if single_hit else 0)
         nb = 0 if big is None else len(big)
-        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), big.ctypes.data if nb else None, nb, int(qid_bound), flags))
+        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), big.ctypes.data if nb else None, nb, int(qid_lo), int(qid_bound), flags))
 
-    def add_batch_host(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False):
+    def add_batch_host(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False, qid_lo: int = 0):
         """Packed tuples in (pinned) host memory the caller keeps alive (see the lifetime rule of mm_annotate_batch)."""
-        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), None, 0, int(qid_bound), _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
+        check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), None, 0, int(qid_lo), int(qid_bound),
+                                      _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
 
     def sync(self):
         check(lib().mm_sync(self._h))

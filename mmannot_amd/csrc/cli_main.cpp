@@ -98,12 +98,16 @@ struct GlibcRand {
 // library's copy stream drains the two submitted before it (a host buffer is free again once the second-next
 // mm_annotate_batch has returned), so H2D copies, kernels and decoding overlap and nothing waits per batch.
 struct Staging {
-  static constexpr size_t BATCH = 1 << 22;
+  // tuples per batch; MM_CLI_BATCH overrides it (tests: many small batches through the asynchronous pipeline)
+  static size_t batch() {
+    static const size_t b = [] { const char *e = getenv("MM_CLI_BATCH"); const long v = e ? atol(e) : 0; return v >= 64 ? (size_t) v : (size_t) 1 << 22; }();
+    return b;
+  }
   mm_aln *buf[3] = {nullptr, nullptr, nullptr};
   std::vector<mm_nh_big> big;
   std::vector<uint64_t> hm;
   bool ok() const { return buf[0] && buf[1] && buf[2]; }
-  Staging() { for (auto &b : buf) b = (mm_aln *) mm_host_alloc(BATCH * sizeof(mm_aln)); big.resize(1 << 16); }
+  Staging() { for (auto &b : buf) b = (mm_aln *) mm_host_alloc(batch() * sizeof(mm_aln)); big.resize(1 << 16); }
   ~Staging() { for (auto &b : buf) mm_host_free(b); }
 };
 
@@ -280,7 +284,7 @@ int main(int argc, char **argv) {
   for (int32_t e = 0; e < E; ++e) elem_names.push_back(mm_annotation_element_name(an, e));
 
   std::map<uint64_t, std::vector<unsigned>> table;  // element set -> one column per input (TableCount::regionCounts, :1858)
-  const size_t BATCH = Staging::BATCH;
+  const size_t BATCH = Staging::batch();
   // One input file on one context.  `err` is std::cerr itself when files are taken one after the other, and a buffer that is
   // printed in command-line order afterwards when several are in flight (-t): the reference's threads interleave their
   // messages as they come; here the text is always the one a -t 1 run prints.
@@ -387,7 +391,7 @@ int main(int argc, char **argv) {
       if (n == 0) break;
       // asynchronous: the copy and the kernels of this batch run while the next one is decoded; only the sequential side
       // channels (-m / -M / -y random), which read per-hit results back, wait for the batch
-      if (mm_annotate_batch(ctx, aln, n, stg.big.data(), n_big, mm_reader_qid_bound(rd), max_nh <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK ||
+      if (mm_annotate_batch(ctx, aln, n, stg.big.data(), n_big, mm_reader_qid_lo(rd), mm_reader_qid_bound(rd), max_nh <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK ||
           (host_book && mm_sync(ctx) != MM_OK)) {
         err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
       }
@@ -511,6 +515,7 @@ int main(int argc, char **argv) {
     if (!decode.ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     std::vector<size_t> submitted(N, 0), part_n(N), part_nbig(N);
     std::vector<uint32_t> part_max(N);
+    std::vector<uint64_t> part_qlo(N);
     std::vector<mm_aln *> part_out(N);
     std::vector<mm_nh_big *> part_big(N);
     const bool ratio = strategy == MM_STRAT_RATIO;
@@ -529,16 +534,16 @@ int main(int argc, char **argv) {
       t_decode += secs(t0, t1); n_records += n;
       if (n == 0) break;
       if (ratio) {
-        if (mm_annotate_batch(ctxs[dr], aln, n, big.data(), n_big, 0, 0) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+        if (mm_annotate_batch(ctxs[dr], aln, n, big.data(), n_big, 0, 0, 0) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
         ++submitted[dr];
       } else {
         for (size_t d = 0; d < N; ++d) { part_out[d] = stg[d].buf[submitted[d] % 3]; part_big[d] = stg[d].big.data(); }
         if (mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg[0].big.size(), part_nbig.data(),
-                         part_max.data()) != MM_OK) { err << "mmannot-amd: cannot deal the batch out to the devices" << std::endl; return EXIT_FAILURE; }
+                         part_max.data(), part_qlo.data()) != MM_OK) { err << "mmannot-amd: cannot deal the batch out to the devices" << std::endl; return EXIT_FAILURE; }
         const uint64_t qb = (mm_reader_qid_bound(rd) + N - 1) / N;
         for (size_t d = 0; d < N; ++d) {
           if (part_n[d] == 0) continue;
-          if (mm_annotate_batch(ctxs[d], part_out[d], part_n[d], part_big[d], part_nbig[d], qb, part_max[d] <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK) {
+          if (mm_annotate_batch(ctxs[d], part_out[d], part_n[d], part_big[d], part_nbig[d], part_qlo[d], qb, part_max[d] <= 1 ? MM_BATCH_SINGLE_HIT : 0) != MM_OK) {
             err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE;
           }
           ++submitted[d];

@@ -142,7 +142,7 @@ struct GlobalTable {
   double *sum;   // -y ratio accumulator (file-order double adds, mmannot.cpp:1730)
   u32 *err;      // ERR_* of the first problem a kernel met (0 = none); read by mm_sync
 };
-enum { ERR_TABLE_FULL = 1, ERR_QID_BOUND = 2, ERR_SINGLE_HIT = 3, ERR_NH_LIST = 4 };
+enum { ERR_TABLE_FULL = 1, ERR_QID_BOUND = 2, ERR_SINGLE_HIT = 3, ERR_NH_LIST = 4, ERR_QID_LO = 5 };
 
 // mm_aln.tsn = strand:1 | NH:11 | (chromosome + 1):20 (include/mmannot_amd.h)
 #define TSN_TID1(z) ((u32) (z) >> (MM_ALN_NH_BITS + 1))
@@ -573,7 +573,7 @@ __device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, const uint2 *ch
 //   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
 template <int OVL>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
-                                               int single, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
+                                               int single, u32 qlo, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
                                                u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
                                                u64 *__restrict__ walkstat) {
   __shared__ LdsTable T;
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     u32 key = NO_KEY, pay = GT_NO_SLOT;
     if (grouped) {
       key = (u32) a.w;
+      if (key < qlo) atomicCAS(G.err, 0u, (u32) ERR_QID_LO);   // the caller's qid_lo hint sized the launches of this batch
       qinv = max(qinv, ~key); qmax = max(qmax, key);
       if (nh >= 0xFFFFu) bigNh = 1;
     }
@@ -1207,6 +1208,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   lds_table_flush(T, G);
 }
 
+// per-batch scalars before k_probe: all zero - or, when the host already knows that the batch's key range fits the leaf layout
+// (qid_lo / qid_bound of mm_annotate_batch), the lower bound as the rebasing origin and "take the leaf path" (no order check:
+// within 21 key bits one partition pass + k_leaf cost no more than the compaction + k_chunk_default of name-grouped input)
+__global__ void k_set_info(u32 *__restrict__ info, u32 qinv, u32 unsorted) {
+  if (threadIdx.x < INFO_WORDS) info[threadIdx.x] = threadIdx.x == INFO_QINV ? qinv : (threadIdx.x == INFO_UNSORTED ? unsorted : 0u);
+}
+
 // ----------------------------------------------------------------------------- k_leaf: multi-hit countdown / union per bucket, in LDS
 // "Leaf" layout (see batch_layout): the partition pass has brought the batch's multi-hit records together by bucket = 4096
 // consecutive read names, file order kept inside a bucket.  One workgroup takes a bucket:
@@ -1224,16 +1232,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_leaf(
     const u64 *__restrict__ recs, const u32 *__restrict__ info, const u32 *__restrict__ base, const int4 *__restrict__ aln,
     const uint2 *__restrict__ big, u32 nbig, const u64 *__restrict__ hm, u32 *__restrict__ grpRem, u64 *__restrict__ grpU, u64 qcap,
-    GlobalTable G, u64 *__restrict__ stats) {
+    GlobalTable G, u64 *__restrict__ stats, int forced) {
   __shared__ LdsTable T;
   __shared__ u64 sU[LEAF_NAMES];     // A: union of the name's sets in this batch; C: the name's union so far
   __shared__ u32 sCnt[LEAF_NAMES];   // A: records of the name in this batch;      C: the name's remaining count
   __shared__ u32 sOA[LEAF_NAMES];    // A: AND << 16 | OR of the name's NH values;  C: LEAF_ILL marks the names being replayed
   __shared__ u32 sOpened, sRescued, sIll;
-  if (!batch_is_leaf(info)) return;                      // this batch is k_chunk_default's
+  const u32 M = info[INFO_M];
+  if (M == 0) return;
+  if (!batch_is_leaf(info)) {                            // this batch is k_chunk_default's - unless the host counted on the leaf layout
+    // (forced: the caller's qid_lo / qid_bound promised a key range of at most 21 bits and only this kernel was launched)
+    if (forced && threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND);
+    return;
+  }
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
   if ((u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
-  const u32 M = info[INFO_M];
   const u32 qmin = ~info[INFO_QINV];
   const u32 nbk = ((info[INFO_QMAX] - qmin) >> LEAF_BITS) + 1u;      // <= RS_BINS by the layout's definition
   const bool by_index = info[INFO_BIGNH] != 0;
@@ -1996,6 +2009,9 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     u64 nonEmpty = 0;
     for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k]) ? 1 : 0;
     if ((double) (ns - nonEmpty) < 0.42 * (double) ns) slotBits.clear();
+    // (Measured and rejected, round 2: storing the non-empty bins only - slot found through a running count kept beside each bitmap
+    // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
+    // SLOWER (0.354 -> 0.394 ms per 2^24 tuples): the rank arithmetic sits on the dependent chain and costs the 64-VGPR budget a spill.)
     ix->n_slots = ns; ix->n_flat = off[ns]; ix->n_slotBits = slotBits.size();
   }
   std::vector<uint4> chrInfo(n_chromosomes);
@@ -2245,7 +2261,8 @@ static int stage_big(mm_ctx *c, const mm_nh_big *big, size_t n_big, size_t n, co
   return MM_OK;
 }
 
-extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_bound, uint32_t flags) {
+extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo, uint64_t qid_bound,
+                                 uint32_t flags) {
   if (!c) return fail(MM_ERR_ARG, "mm_annotate_batch: null context");
   if (c->finalized) return fail(MM_ERR_STATE, "mm_annotate_batch: context already finalized (call mm_reset)");
   if (n == 0) return MM_OK;
@@ -2254,6 +2271,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   if (flags & ~(uint32_t) (MM_BATCH_ON_DEVICE | MM_BATCH_SINGLE_HIT)) return fail(MM_ERR_ARG, "mm_annotate_batch: unknown flag");
   const bool on_device = (flags & MM_BATCH_ON_DEVICE) != 0, single = (flags & MM_BATCH_SINGLE_HIT) != 0;
   if (single && n_big) return fail(MM_ERR_ARG, "mm_annotate_batch: MM_BATCH_SINGLE_HIT with an NH side list");
+  if (qid_lo > qid_bound || qid_lo > 0xFFFFFFF0ull) qid_lo = 0;   // (a hint only)
   HIPCHK(hipSetDevice(c->ix->device));
   int rc = ensure_batch(c, n, !on_device);
   if (rc) return rc;
@@ -2289,21 +2307,26 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
   u64 *hm = c->d_hm;
   u32 *gkey = need_groups ? c->d_gkey : nullptr;
-  if (need_groups) HIPCHK(hipMemsetAsync(c->d_M, 0, INFO_WORDS * 4, c->stream));
+  // host-known key range of this batch's multi-hit records: within the leaf layout's reach?  Then that path is taken for granted
+  const int span_bits = dflt ? bits_for((qid_bound ? qid_bound : 1) - qid_lo) : 16;
+  const bool force_leaf = dflt && need_groups && span_bits <= LEAF_BITS + LEAF_DIGIT_BITS;
+  if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
   PhaseTimer t(c, MM_PHASE_PROBE);
   switch (c->opt.overlap_mode) {
     case MM_OVL_INCLUSION:
-      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     case MM_OVL_PC:
-      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
       break;
     default:
-      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
   }
   }
-  if (dflt && need_groups && !c->opt.keep_hit_masks) {   // (returns at once unless the batch holds an NH >= 65535)
+  bool huge_nh = false;                                  // an NH >= 65535 can only come through the side list
+  for (size_t k = 0; k < n_big && !huge_nh; ++k) huge_nh = big[k].nh >= 0xFFFFu;
+  if (dflt && need_groups && !c->opt.keep_hit_masks && huge_nh) {
     switch (c->opt.overlap_mode) {
       case MM_OVL_INCLUSION:
         hipLaunchKernelGGL(k_probe_sets<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, n, hm, c->d_M, c->G.err);
@@ -2321,7 +2344,9 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   if (need_groups) {
     {
       PhaseTimer t(c, MM_PHASE_SORT);
-      rc = sort_pairs(c, n, dflt ? bits_for(qid_bound ? qid_bound : 1) : 16, dflt ? 0 : 16, dflt ? 1 : 0);
+      // passes to launch: from the widest key range this batch can have (the kernels of a pass the actual range does not need
+      // return at once); within LEAF_BITS + LEAF_DIGIT_BITS bits the one partition pass of the leaf layout is all there is
+      rc = sort_pairs(c, n, force_leaf ? 8 : span_bits, dflt ? 0 : 16, dflt ? 1 : 0);
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
@@ -2329,7 +2354,8 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       // exactly one of the two does the work (device-side decision, batch_is_leaf): k_leaf behind the partition pass of the leaf
       // layout, k_chunk_default behind the full sort or - name-grouped input - the plain compaction
       hipLaunchKernelGGL(k_leaf, dim3(RS_BINS), dim3(LEAF_THREADS), 0, c->stream, (const u64 *) c->d_kB, c->d_M, c->d_rowTot, d_aln, d_big, (u32) n_big, hm,
-                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
+                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, force_leaf ? 1 : 0);
+      if (!force_leaf)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_aln, d_big, (u32) n_big, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
     } else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
@@ -2356,6 +2382,7 @@ static int check_table(mm_ctx *c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (err == ERR_QID_BOUND) return fail(MM_ERR_ARG, "a read-name id (qid) of the batch is not below the qid_bound given to mm_annotate_batch; the batch's multi-hit records were not merged");
   if (err == ERR_SINGLE_HIT) return fail(MM_ERR_ARG, "a batch submitted with MM_BATCH_SINGLE_HIT holds a tuple with NH > 1");
+  if (err == ERR_QID_LO) return fail(MM_ERR_ARG, "a tuple with NH > 1 has a read-name id below the qid_lo hint given to mm_annotate_batch");
   if (err == ERR_NH_LIST) return fail(MM_ERR_ARG, "a tuple's NH field is MM_ALN_NH_ESCAPE but the batch's NH side list has no entry for it");
   if (err) return fail(MM_ERR_TABLE_FULL, "more than 65535 distinct element sets");
   return MM_OK;

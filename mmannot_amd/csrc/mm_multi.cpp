@@ -18,9 +18,9 @@
 #include "../../include/mmannot_amd.h"
 
 extern "C" int mm_partition(const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, int n_parts, mm_aln *const *out, size_t *out_n,
-                            mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh) {
+                            mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh, uint64_t *out_qid_lo) {
   if (n_parts < 1 || !out || !out_n || (n && !aln) || (n_big && (!big || !out_big || !out_n_big))) return MM_ERR_ARG;
-  for (int p = 0; p < n_parts; ++p) { out_n[p] = 0; if (out_n_big) out_n_big[p] = 0; if (out_max_nh) out_max_nh[p] = 0; }
+  for (int p = 0; p < n_parts; ++p) { out_n[p] = 0; if (out_n_big) out_n_big[p] = 0; if (out_max_nh) out_max_nh[p] = 0; if (out_qid_lo) out_qid_lo[p] = ~0ull; }
   size_t bi = 0;
   const uint32_t N = (uint32_t) n_parts;
   for (size_t i = 0; i < n; ++i) {
@@ -39,7 +39,9 @@ extern "C" int mm_partition(const mm_aln *aln, size_t n, const mm_nh_big *big, s
       nh = big[bi].nh;
     }
     if (out_max_nh && nh > out_max_nh[p]) out_max_nh[p] = nh;
+    if (out_qid_lo && nh > 1 && a.qid < out_qid_lo[p]) out_qid_lo[p] = a.qid;
   }
+  if (out_qid_lo) for (int p = 0; p < n_parts; ++p) if (out_qid_lo[p] == ~0ull) out_qid_lo[p] = 0;
   return MM_OK;
 }
 
@@ -79,7 +81,11 @@ extern "C" int mm_merge(mm_ctx *const *ctxs, int n_ctx, int strategy, uint64_t *
       first = false;
     }
     for (int k = 0; k < n_ctx; ++k) if (mm_ratio_pending(ctxs[k]) != 0) return MM_ERR_STATE;   // batches were not dealt round-robin from ctxs[0]
-    if (first) { const int rc = rows_of(ctxs[0]); if (rc) return rc; }
+    if (first) { const int rc = rows_of(ctxs[0]); if (rc) return rc; }   // nothing parked (any more): every context holds the final rows
+    else for (int k = 0; k < n_ctx; ++k) {   // leave the input's final sums in every context (a second call - sizes first, rows then - finds them)
+      const int rc = m.empty() ? MM_OK : mm_set_row_sums(ctxs[k], m.data(), v.data(), m.size());
+      if (rc) return rc;
+    }
   } else if (n_ctx == 1) {
     const int rc = rows_of(ctxs[0]);
     if (rc) return rc;

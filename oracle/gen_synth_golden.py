@@ -77,6 +77,13 @@ def main():
             _, _, bam2 = make_inputs(w2, d2)
             rc, so, se = mo.run_ref("mmannot_patched", ["-a", gtf, "-c", cfg, "-s", "F", "-r", bam, bam2, "-n", "first", "second"])
             out[name + "_two_files"] = dict(workload=w, workload2=w2, rc=rc, stdout=so, stderr=se.replace(d, "$D").replace(d2, "$E"))
+            # -y random over several files: rand() runs on and the Counter's seen / chosenId / numberSeen maps (keyed by read name)
+            # survive Counter::clear (mmannot.cpp:1742-1747), so later columns depend on the earlier files (the two BAMs share names)
+            rnd = []
+            for files, tag in (([bam, bam2], "ab"), ([bam2, bam, bam2], "bab")):
+                rc, so, se = mo.run_ref("mmannot_patched", ["-a", gtf, "-c", cfg, "-s", "U", "-y", "random", "-r"] + files)
+                rnd.append(dict(files=tag, rc=rc, stdout=so, stderr=se.replace(d, "$D").replace(d2, "$E")))
+            out[name + "_two_files_random"] = dict(workload=w, workload2=w2, runs=rnd)
         out[name] = dict(workload=w, cases=cases)
     json.dump(out, open(os.path.join(GOLD, "cases.json"), "w"), indent=1)
 

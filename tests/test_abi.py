@@ -29,8 +29,15 @@ def test_host_finalisation_helpers(oracle):
     """mm_round_to_uint / mm_sort_rows are host code: compare with the oracle's restatement."""
     from mmannot_amd import _lib
     l = _lib.lib()
-    for v in (0.0, 0.49999999999999994, 0.5, 1.5, 2.5, 1e9 + 0.5, 4294967295.6, 4294967296.0, float("inf"), float("nan")):
-        assert l.mm_round_to_uint(v) == oracle.lib().mmo_round_to_uint(v)
+    # `unsigned int v = round(double)` of the reference's x86-64 build (mmannot.cpp:1868): round half away from zero, cvttsd2si to
+    # 64 bits ("integer indefinite" = 0x8000000000000000 for inf / nan / |v| >= 2^63), low 32 bits kept.  Known answers written out
+    # by hand (KAT E4 pins the inf case through the reference itself); the oracle's restatement must agree as well.
+    known = {0.0: 0, 0.49999999999999994: 0, 0.5: 1, 1.5: 2, 2.5: 3, 1e9 + 0.5: 1000000001, 4294967295.4: 4294967295, 4294967295.6: 0,
+             4294967296.0: 0, 4294967297.0: 1, -0.4: 0, -1.0: 4294967295, -2.5: 4294967293, 9.2e18: 9200000000000000000 % (1 << 32),
+             9.3e18: 0, -9.3e18: 0, float("inf"): 0, float("-inf"): 0, float("nan"): 0}
+    for v, want in known.items():
+        assert l.mm_round_to_uint(v) == want, v
+        assert oracle.lib().mmo_round_to_uint(v) == want, v
     rng = np.random.default_rng(5)
     masks = np.unique(rng.integers(1, 1 << 22, 500, dtype=np.uint64) & rng.integers(1, 1 << 22, 500, dtype=np.uint64))
     masks = masks[masks != 0]

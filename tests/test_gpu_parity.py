@@ -92,7 +92,7 @@ def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
 
 def test_name_grouped_input(gpu_lib, oracle):
     """An aligner's own output keeps the hits of a read adjacent, so read-name ids are non-decreasing and the name sort is
-    skipped (k_rs_hist's order check).  Same answers as the oracle, malformed groups included; and one inversion anywhere -
+    skipped (k_rs_hist's order check; it matters when the batch's key range is too wide for the one-pass leaf layout).  Same answers as the oracle, malformed groups included; and one inversion anywhere -
     inside a wave, or across the wave (64) / round (512) / tile (8192) boundaries of the check - must send the batch down
     the general path and still give the oracle's answer."""
     mm = gpu_lib
@@ -116,7 +116,9 @@ def test_name_grouped_input(gpu_lib, oracle):
 
     for nh_min in (1, 2):
         reads = sr.random_reads(rng, ix, n=21000, nchr=3, maxpos=120000, nh_max=7, shuffle=False, nh_min=nh_min)
-        assert (np.diff(reads["qid"]) >= 0).all()
+        # (ids spread out: within 21 key bits the library takes the partition + k_leaf path without looking at the order at all)
+        reads = dict(reads, qid=reads["qid"] * 1000)
+        assert (np.diff(reads["qid"]) >= 0).all() and int(reads["qid"].max()) > (1 << 22)
         ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="U", strategy="default")
         for batches in (1, 4):
             rows, st, grouped = gpu(reads, batches)

@@ -97,3 +97,23 @@ def test_kat_cli(gpu_lib, tmp_path, name):
             assert sorted(open(mfile).read().splitlines()) == sorted(c["mfile"].splitlines())
         if c.get("mmfile") is not None:  # -M output is sorted by the reference: byte-exact
             assert open(mmfile).read() == c["mmfile"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_kat_cli_two_devices(gpu_lib, tmp_path, name):
+    """The known-answer cases with the one input file sharded over two contexts (--devices 0,0), two tuples per batch."""
+    d, reads, cases = load(name)
+    env = dict(os.environ, MM_CLI_BATCH="64")
+    for c in cases:
+        if any(a in ("-m", "-M") for a in c["args"]) or "random" in c["args"]:
+            continue
+        args = list(c["args"])
+        if c["variant"] == "verbatim":
+            args += ["--compat-strand", "plus"]
+        out = str(tmp_path / "t.tsv")
+        p = subprocess.run([CLI, "-a", os.path.join(d, "a.gtf"), "-r", reads, "-c", os.path.join(d, "c.cfg"), "-o", out, "--devices", "0,0"] + args,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+        assert p.returncode == c["rc"], p.stderr.decode()
+        assert open(out).read() == c["table"], (c["args"], p.stderr.decode())
+        assert p.stderr.decode().replace(d, "$D") == c["stderr"], c["args"]

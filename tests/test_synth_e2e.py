@@ -95,3 +95,46 @@ def test_cli_files_in_flight(gpu_lib, inputs, tmp_path, extra):
     assert p.returncode == c["rc"], p.stderr.decode()
     assert p.stdout.decode() == c["stdout"]
     assert p.stderr.decode().replace(d2, "$E").replace(d, "$D") == c["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SINGLE)
+@pytest.mark.parametrize("devices,batch", [("0,0", None), ("0,0,0", "7001"), ("0", "7001")])
+def test_cli_one_input_on_several_devices(gpu_lib, inputs, name, devices, batch):
+    """--devices a,b,.. with ONE -r file shards its reads: -y default / unique deal the tuples out by read name (mm_partition), -y ratio
+    sends whole batches round-robin and chains the file-order double sums (mm_merge).  Same table and stderr block as one device, also
+    when the file arrives in many small batches (MM_CLI_BATCH; with one device this exercises the asynchronous pipeline alone)."""
+    d, gtf, cfg, bam = inputs[name]
+    env = dict(os.environ)
+    if batch:
+        env["MM_CLI_BATCH"] = batch
+    ran = 0
+    for c in CASES[name]["cases"]:
+        if "-m" in c["args"] or "-M" in c["args"] or "random" in c["args"]:
+            continue                     # the sequential side channels stay on one device
+        out = os.path.join(d, "t_multi.tsv")
+        p = subprocess.run([CLI, "-a", gtf, "-r", bam, "-c", cfg, "-o", out, "--devices", devices] + list(c["args"]),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+        assert p.returncode == c["rc"], p.stderr.decode()
+        assert open(out).read() == c["table"], c["args"]
+        assert p.stderr.decode().replace(d, "$D") == c["stderr"], c["args"]
+        ran += 1
+    assert ran > 0
+
+
+@pytest.mark.gpu
+def test_cli_random_over_several_files(gpu_lib, inputs, tmp_path):
+    """-y random with several -r files (taken one after the other): rand() runs on across the files and a read name already output
+    in an earlier file is never output again (the reference's Counter keeps seen / chosenId / numberSeen through clear(),
+    mmannot.cpp:1742-1747).  Every column equals the compiled reference's."""
+    from oracle import gen_synth_golden as g
+    c = CASES["tair10_two_files_random"]
+    d, gtf, cfg, bam = inputs["tair10"]
+    d2 = str(tmp_path)
+    _, _, bam2 = g.make_inputs(c["workload2"], d2)
+    for run in c["runs"]:
+        files = [bam if ch == "a" else bam2 for ch in run["files"]]
+        p = subprocess.run([CLI, "-a", gtf, "-c", cfg, "-s", "U", "-y", "random", "-r"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == run["rc"], p.stderr.decode()
+        assert p.stdout.decode() == run["stdout"], run["files"]
+        assert p.stderr.decode().replace(d2, "$E").replace(d, "$D") == run["stderr"]
