@@ -137,6 +137,10 @@ def main():
             return 0
         return (step * B // (nh_max * (nh_max + 1) // 2)) * nh_max
 
+    def qbound(step):   # exclusive bound of the read-name ids seen up to and including this batch (what a decoder reports: its dictionary's size)
+        return min(qb, qlo(step + 1) + 2 * nh_max + 2)
+    ctr.reserve(qb)
+
     def run_leg(from_host: bool):
         """W warm-up steps, then K timed steps + end-of-file flush + cross-rank merge, bracketed by barrier + synchronize.
         Returns (elapsed seconds = max over ranks, phases of the timed region, masks, sums, stats)."""
@@ -148,9 +152,9 @@ def main():
 
         def step(s):
             if host is not None:
-                ctr.add_batch_host(host[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
+                ctr.add_batch_host(host[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
             else:
-                ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
+                ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
 
         for s in range(args.warmup):
             step(s)
@@ -205,11 +209,11 @@ def main():
     else:
         ctr.clear()
         for s in range(args.warmup):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
+            ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         ctr.set_profiling(1)
         for s in range(args.warmup, args.warmup + n_phase):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qb, single_hit=single, qid_lo=qlo(s))
+            ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         phases_all = ctr.phase_ms()
         ctr.set_profiling(0)

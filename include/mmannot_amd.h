@@ -131,6 +131,9 @@ int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options *opt, void 
 void mm_ctx_destroy(mm_ctx *ctx);
 /* Counter::clear(), mmannot.cpp:1742-1747 */
 int mm_reset(mm_ctx *ctx);
+/* optional: size the per-read-name state of -y default for qid_bound names ahead of time (a caller that knows how many reads are to
+ * come), so that mm_annotate_batch never has to grow it in the middle of a stream */
+int mm_reserve_qids(mm_ctx *ctx, uint64_t qid_bound);
 
 /* One batch of the per-alignment loop of Counter::read (mmannot.cpp:1772-1781): for every tuple,
  * scan() then addCount().  Asynchronous on the context's stream.

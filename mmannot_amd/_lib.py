@@ -61,6 +61,7 @@ SYMBOLS = {
     "mm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Options), C.c_void_p]),
     "mm_ctx_destroy": (None, [C.c_void_p]),
     "mm_reset": (C.c_int, [C.c_void_p]),
+    "mm_reserve_qids": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32]),
     "mm_host_alloc": (C.c_void_p, [C.c_size_t]),
     "mm_host_free": (None, [C.c_void_p]),

@@ -189,6 +189,10 @@ class Counter:
     def clear(self):  # Counter::clear mmannot.cpp:1742-1747
         check(lib().mm_reset(self._h))
 
+    def reserve(self, qid_bound: int):
+        """Size the per-read-name state ahead of time (optional)."""
+        check(lib().mm_reserve_qids(self._h, int(qid_bound)))
+
     def add_batch(self, aln: np.ndarray, nh: Optional[np.ndarray], qid_bound: int, single_hit: Optional[bool] = None, qid_lo: int = 0):
         """Host tuples (mm_aln structured array) -> one batch of the loop of Counter::read (mmannot.cpp:1772-1781).
         nh given: the NH of every tuple (packed into a copy of the tuples, values beyond the field into the side list);

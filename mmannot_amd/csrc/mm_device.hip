@@ -777,7 +777,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const u32 k = kk[r];
     const bool ok = (okm >> r) & 1u;
-    wave_hist_add<0>(h, batch_digit(k, L, shift), ok, fixed_bits != 0);
+    // (leaf layout: the digit is the bucket, 4096 consecutive names - the hits of a read lie close together in most inputs, so a tile
+    // sees a handful of buckets: same-address LDS atomics unless the wave's equal digits are counted together)
+    wave_hist_add<0>(h, batch_digit(k, L, shift), ok, fixed_bits != 0 || L.leaf);
     if (chk) {   // wave-uniform
       const u64 vm = __ballot(ok);
       const u64 below = vm & ((1ull << lane) - 1ull);
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     if (presorted) {   // (wave-uniform) all pairs count for digit 0: one add per wave instead of 64 colliding atomics
       const u32 c = (u32) __popcll(__ballot(ok));
       if (lane == 0) cntw[w][0] = (unsigned short) (cntw[w][0] + c);
-    } else wave_hist_add<1>((u32 *) cntw[w], batch_digit(kreg[r], L, shift), ok, fixed_bits != 0);
+    } else wave_hist_add<1>((u32 *) cntw[w], batch_digit(kreg[r], L, shift), ok, fixed_bits != 0 || L.leaf);
   }
   __syncthreads();
   if (presorted) {   // plain ordered compaction: the pairs go straight from the registers to their place, in file order
@@ -2108,6 +2110,13 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   }
   if (c->own_stream) (void) hipStreamDestroy(c->stream);
   delete c;
+}
+
+static int ensure_qids(mm_ctx *c, u64 qid_bound);
+extern "C" int mm_reserve_qids(mm_ctx *c, uint64_t qid_bound) {
+  if (!c) return fail(MM_ERR_ARG, "mm_reserve_qids: null context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  return c->opt.strategy == MM_STRAT_DEFAULT ? ensure_qids(c, qid_bound ? qid_bound : 1) : MM_OK;
 }
 
 extern "C" int mm_reset(mm_ctx *c) {

@@ -26,6 +26,7 @@
 #include <thread>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -39,6 +40,58 @@ using namespace mmh;
 namespace {
 
 struct CigarOp { char op; int len; };
+
+// A handful of threads that stay alive between parallel steps: worker w of one step is worker w of the next, so what it left in
+// its core's cache (the blocks it inflated, the sub-dictionary it owns) is still there when it comes back.
+struct Pool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::function<void(int)> job;
+  int W = 0, remaining = 0;
+  uint64_t gen = 0;
+  bool stop = false;
+  void start(int n) {
+    if (W) return;
+    W = n < 1 ? 1 : n;
+    for (int w = 1; w < W; ++w) th.emplace_back([this, w] { loop(w); });
+  }
+  void loop(int w) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen; f = job;
+      }
+      f(w);
+      std::lock_guard<std::mutex> lk(mu);
+      if (--remaining == 0) done_cv.notify_one();
+    }
+  }
+  // f(w) for w = 0..W-1, f(0) on the calling thread; returns when all are done
+  void run(const std::function<void(int)> &f) {
+    if (W <= 1) { f(0); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = f; remaining = W - 1; ++gen;
+    }
+    cv.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(mu);
+    done_cv.wait(lk, [&] { return remaining == 0; });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
 
 // hash of a read name (the dictionary's, computed by whoever parses the record)
 static inline uint64_t name_hash(const char *p, size_t n) {
@@ -177,6 +230,7 @@ struct BgzfPipe {
   std::mutex mu;
   std::condition_variable cv;
   std::thread producer;
+  Pool pool;                 // inflates, then parses (worker w: the same blocks' bytes both times)
   bool stop = false;
   int take = 0;
   double t_read = 0, t_inflate = 0, t_frame = 0, t_parse = 0, t_wait_prod = 0, t_wait_cons = 0;   // MM_READER_TIMING=1: printed at close
@@ -287,10 +341,8 @@ struct BgzfPipe {
         }
         inflateEnd(&z);
       };
-      std::vector<std::thread> th;
-      for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-      work(0);
-      for (auto &x : th) x.join();
+      pool.start(n_threads);
+      pool.run(work);
       for (int v : fail) if (v) B.bad = true;
       const double s2 = now();
       t_inflate += s2 - s1;
@@ -339,11 +391,8 @@ struct BgzfPipe {
           };
           const double s3 = now();
           t_frame += s3 - s2;
-          std::vector<std::thread> pt;
-          const int nt = nr >= 4096 ? n_threads : 1;
-          for (int t = 1; t < nt; ++t) pt.emplace_back(parse, t, nt);
-          parse(0, nt);
-          for (auto &x : pt) x.join();
+          if (nr >= 4096) pool.run([&](int t) { parse(t, n_threads); });
+          else parse(0, 1);
           t_parse += now() - s3;
           B.parsed = true;
           if (broken) frame = false;                       // [framed_end, len) and every later batch: raw, for the sequential reader
@@ -573,13 +622,8 @@ struct QidSpace {
   std::vector<std::vector<uint32_t>> bucket, lids;   // [range * NSUB + owner]: record indices / local id | new << 31
   std::vector<uint32_t> newcnt;
   double t_a = 0, t_b = 0, t_c = 0;     // MM_READER_TIMING
-  template <class F>
-  static void parallel(int W, F f) {
-    std::vector<std::thread> th;
-    for (int w = 1; w < W; ++w) th.emplace_back(f, w);
-    f(0);
-    for (auto &t : th) t.join();
-  }
+  Pool pool;                            // worker w always serves the sub-dictionaries o = w (mod W): their tables stay in its cache
+  void parallel(int W, const std::function<void(int)> &f) { pool.start(W); pool.run(f); }
   // ids of the parsed records recs[0..n) (all PR_FAST, names at base + off + 36), in file order -> out[0..n)
   void resolve_run(const ParsedRec *recs, size_t n, const uint8_t *base, uint32_t *out, int n_threads) {
     const int W = std::max(1, std::min(n_threads, 16));
