@@ -139,7 +139,8 @@ def main():
 
     def qbound(step):   # exclusive bound of the read-name ids seen up to and including this batch (what a decoder reports: its dictionary's size)
         return min(qb, qlo(step + 1) + 2 * nh_max + 2)
-    ctr.reserve(qb)
+    if nh_max > 1 and strategy == "default":
+        ctr.reserve(qb)         # the per-read-name state is sized once, before any timing (a decoder that knows the number of reads)
 
     def run_leg(from_host: bool):
         """W warm-up steps, then K timed steps + end-of-file flush + cross-rank merge, bracketed by barrier + synchronize.

@@ -185,6 +185,11 @@ int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
 int mm_set_row_sums(mm_ctx *ctx, const uint64_t *masks, const double *sums, size_t n);
 int mm_ratio_resolve(mm_ctx *ctx);
 int mm_ratio_resolve_n(mm_ctx *ctx, size_t max_runs);   /* replays only the first max_runs parked batches */
+/* Rows are independent of each other, so a chain of ranks can be pipelined: replay all parked batches for the rows of chunk `chunk`
+ * only (mm_row_chunk(mask, n_chunks) == chunk), hand those rows on, go on with the next chunk.  The parked batches are released with
+ * the last chunk. */
+int mm_ratio_resolve_chunk(mm_ctx *ctx, uint32_t chunk, uint32_t n_chunks);
+uint32_t mm_row_chunk(uint64_t mask, uint32_t n_chunks);
 size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet replayed */
 
 /* ---- one input on several GPUs (replaces the reference's thread-per-file pool, mmannot.cpp:2117-2143, which can only

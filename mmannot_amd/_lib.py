@@ -76,6 +76,8 @@ SYMBOLS = {
     "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mm_ratio_pending": (C.c_size_t, [C.c_void_p]),
+    "mm_ratio_resolve_chunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "mm_row_chunk": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "mm_partition": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     "mm_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

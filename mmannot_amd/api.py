@@ -73,6 +73,16 @@ def aln_nh(aln, big=None) -> np.ndarray:
     return nh
 
 
+def row_chunk(masks: np.ndarray, n_chunks: int) -> np.ndarray:
+    """mm_row_chunk for an array of element sets: which chunk of a pipelined -y ratio chain a row belongs to."""
+    m = np.asarray(masks, dtype=np.uint64)
+    if n_chunks <= 1:
+        return np.zeros(len(m), dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        h = ((m * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)).astype(np.uint32)
+    return h % np.uint32(n_chunks)
+
+
 def overlap_mode_of(l: float) -> int:
     """-l: <0 inclusion, <1 fraction of the read, else nucleotides (mmannot.cpp:1972-1977)."""
     l = np.float32(l)
@@ -253,6 +263,10 @@ class Counter:
     def resolve_ratio(self):
         """Replay the batches parked by defer_ratio, in order."""
         check(lib().mm_ratio_resolve(self._h))
+
+    def resolve_ratio_chunk(self, chunk: int, n_chunks: int):
+        """Replay the parked batches for the rows of one chunk only (see row_chunk); the last chunk releases them."""
+        check(lib().mm_ratio_resolve_chunk(self._h, int(chunk), int(n_chunks)))
 
     def hit_masks(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint64)

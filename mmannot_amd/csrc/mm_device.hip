@@ -1448,8 +1448,13 @@ __device__ __forceinline__ u64 ratio_inc(u32 nh, int k) {
 // its integer increments, computed for the binade the row's sum is in when the batch starts.  The whole GPU works on
 // this; k_ratio_rows then consumes a tile in O(1) as long as the binade is still the same and the tile neither holds a
 // tie-capable / infinite term nor leaves the binade, and falls back to its own exact chunk path otherwise.
+// Rows can be accumulated in any order relative to each other (only the terms of ONE row are ordered), so a replay may be cut into
+// "row chunks": chunk c of n holds the rows whose element set hashes to c.  Ranks chaining their sums hand
+// chunk c on while they work on chunk c + 1.
+__device__ __forceinline__ bool row_in_chunk(u64 mask, u32 chunk, u32 nchunks) { return nchunks <= 1 || hash64(mask) % nchunks == chunk; }
+
 __global__ __launch_bounds__(256) void k_ratio_tiles(const u32 *__restrict__ skeys, const u32 *__restrict__ svals, const u32 *__restrict__ info,
-                                                     GlobalTable G, u64 *__restrict__ tileTot, int *__restrict__ tileK) {
+                                                     GlobalTable G, u64 *__restrict__ tileTot, int *__restrict__ tileK, u32 chunk, u32 nchunks) {
   // tileTot[2T], tileK[2T]: summary for the binade k the row is in now; [2T+1]: for binade k+1 (a long row crosses
   // into the next binade at most once per batch, and the tiles behind the crossing then still have a summary)
   __shared__ u64 wsum[2][4];
@@ -1461,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_ratio_tiles(const u32 *__restrict__ ske
   int k = 0x7ffffffe;                                        // "no summary"
   if (lo + RATIO_CHUNK <= M) {
     const u32 key0 = skeys[lo], key1 = skeys[lo + RATIO_CHUNK - 1];
-    if (key0 == key1) {
+    if (key0 == key1 && row_in_chunk(G.key[key0], chunk, nchunks)) {
       const u64 bs = (u64) __double_as_longlong(G.sum[key0]);
       const int E = (int) ((bs >> 52) & 0x7FF);
       if (E != 0 && E != 0x7FF && !(bs >> 63)) k = E - 1023;
@@ -1492,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_ratio_tiles(const u32 *__restrict__ ske
 
 __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restrict__ svals, const u32 *__restrict__ segLo,
                                                               const u32 *__restrict__ segHi, GlobalTable G, const u64 *__restrict__ tileTot,
-                                                              const int *__restrict__ tileK) {
+                                                              const int *__restrict__ tileK, u32 chunk, u32 nchunks) {
   __shared__ u64 lut[RATIO_LUT];
   __shared__ u64 wsum[RATIO_THREADS / 64];
   __shared__ u32 wflag[RATIO_THREADS / 64];
@@ -1513,6 +1518,7 @@ __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restr
     const u32 slot = slot0 + si;
     const u32 lo = sLo[si], hi = sHi[si];
     if (hi <= lo) continue;                                  // block-uniform
+    if (!row_in_chunk(G.key[slot], chunk, nchunks)) continue;  // (block-uniform) another chunk's row
     if (t == 0) sS = G.sum[slot];
     __syncthreads();
     for (u32 cb = lo; cb < hi;) {
@@ -1800,7 +1806,7 @@ struct mm_ctx {
   u32 *d_grpRem = nullptr;
   u64 *d_grpU = nullptr;
   // -y ratio with defer_ratio: each batch's slot-sorted (slot, NH) pairs are parked here until mm_ratio_resolve
-  struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr; size_t n = 0; };
+  struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr, *seg = nullptr; size_t n = 0; };
   std::vector<Run> runs;
   // optional live timing (HIP events on the context's stream), see mm_set_profiling
   int profiling = 0;   // 0 off, 1 every phase, 2 the probe phase only
@@ -2230,20 +2236,29 @@ __global__ __launch_bounds__(256) void k_seed_rows(const u64 *__restrict__ masks
   if (s != NO_KEY) G.sum[s] = sums[i];
 }
 
-// ordered accumulation of one batch's slot-sorted pairs (see k_ratio_rows)
-static int ratio_accumulate(mm_ctx *c, const u32 *keys, const u32 *vals, const u32 *info, size_t n) {
+// segment bounds of every slot in one batch's slot-sorted pairs -> seg[0..GT_CAP) lows, seg[GT_CAP..2 GT_CAP) highs
+static int ratio_bounds(mm_ctx *c, const u32 *keys, const u32 *info, size_t n, u32 *seg) {
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
-  HIPCHK(hipMemsetAsync(c->d_seg, 0, 2 * GT_CAP * 4, c->stream));
-  hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, keys, info, c->d_seg, c->d_seg + GT_CAP);
-  hipLaunchKernelGGL(k_ratio_tiles, dim3((u32) (n / RATIO_CHUNK + 1)), dim3(256), 0, c->stream, keys, vals, info, c->G, c->d_tileTot, c->d_tileK);
-  hipLaunchKernelGGL(k_ratio_rows, dim3(GT_CAP / RATIO_SLOTS_PER_WG), dim3(RATIO_THREADS), 0, c->stream, vals, c->d_seg, c->d_seg + GT_CAP, c->G,
-                     c->d_tileTot, c->d_tileK);
+  HIPCHK(hipMemsetAsync(seg, 0, 2 * GT_CAP * 4, c->stream));
+  hipLaunchKernelGGL(k_seg_bounds, dim3(grid), dim3(256), 0, c->stream, keys, info, seg, seg + GT_CAP);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+// ordered accumulation of one batch's slot-sorted pairs (see k_ratio_rows); seg = the batch's bounds if already known; rows of one
+// chunk only when nchunks > 1
+static int ratio_accumulate(mm_ctx *c, const u32 *keys, const u32 *vals, const u32 *info, size_t n, const u32 *seg = nullptr, u32 chunk = 0,
+                            u32 nchunks = 1) {
+  if (!seg) { const int rc = ratio_bounds(c, keys, info, n, c->d_seg); if (rc) return rc; seg = c->d_seg; }
+  hipLaunchKernelGGL(k_ratio_tiles, dim3((u32) (n / RATIO_CHUNK + 1)), dim3(256), 0, c->stream, keys, vals, info, c->G, c->d_tileTot, c->d_tileK, chunk, nchunks);
+  hipLaunchKernelGGL(k_ratio_rows, dim3(GT_CAP / RATIO_SLOTS_PER_WG), dim3(RATIO_THREADS), 0, c->stream, vals, seg, seg + GT_CAP, c->G,
+                     c->d_tileTot, c->d_tileK, chunk, nchunks);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }
 
 static void free_runs(mm_ctx *c) {
-  for (auto &r : c->runs) { (void) hipFree(r.k); (void) hipFree(r.v); (void) hipFree(r.info); }
+  for (auto &r : c->runs) { (void) hipFree(r.k); (void) hipFree(r.v); (void) hipFree(r.info); (void) hipFree(r.seg); }
   c->runs.clear();
 }
 
@@ -2374,7 +2389,10 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       HIPCHK(hipMemcpyAsync(r.k, c->d_kA, n * 4, hipMemcpyDeviceToDevice, c->stream));
       HIPCHK(hipMemcpyAsync(r.v, c->d_vA, n * 4, hipMemcpyDeviceToDevice, c->stream));
       HIPCHK(hipMemcpyAsync(r.info, c->d_M, INFO_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMalloc((void **) &r.seg, 2 * GT_CAP * 4));       // every slot's segment of this batch: known now, off the chain's critical path
       c->runs.push_back(r);
+      rc = ratio_bounds(c, r.k, r.info, n, r.seg);
+      if (rc) return rc;
     } else {
       rc = ratio_accumulate(c, c->d_kA, c->d_vA, c->d_M, n);
       if (rc) return rc;
@@ -2443,17 +2461,34 @@ extern "C" int mm_ratio_resolve_n(mm_ctx *c, size_t max_runs) {
   for (auto &r : c->runs) {
     if (done == max_runs) break;
     PhaseTimer t(c, MM_PHASE_MERGE);
-    int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n);
+    int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n, r.seg);
     if (rc) return rc;
     ++done;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (size_t k = 0; k < done; ++k) { (void) hipFree(c->runs[k].k); (void) hipFree(c->runs[k].v); (void) hipFree(c->runs[k].info); }
+  for (size_t k = 0; k < done; ++k) { (void) hipFree(c->runs[k].k); (void) hipFree(c->runs[k].v); (void) hipFree(c->runs[k].info); (void) hipFree(c->runs[k].seg); }
   c->runs.erase(c->runs.begin(), c->runs.begin() + (long) done);
   return check_table(c);
 }
 
 extern "C" int mm_ratio_resolve(mm_ctx *c) { return mm_ratio_resolve_n(c, (size_t) -1); }
+
+// Replays every parked batch for the rows of ONE chunk (of n_chunks, by the hash of the row's element set); the parked batches are
+// released with the last chunk.  A rank of a chain can so pass chunk c's sums on while it works on chunk c + 1.
+extern "C" int mm_ratio_resolve_chunk(mm_ctx *c, uint32_t chunk, uint32_t n_chunks) {
+  if (!c || n_chunks == 0 || chunk >= n_chunks) return fail(MM_ERR_ARG, "mm_ratio_resolve_chunk: bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  for (auto &r : c->runs) {
+    PhaseTimer t(c, MM_PHASE_MERGE);
+    const int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n, r.seg, chunk, n_chunks);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (chunk + 1 == n_chunks) free_runs(c);
+  return check_table(c);
+}
+/* chunk of a row, for callers that split mm_get_rows by chunk */
+extern "C" uint32_t mm_row_chunk(uint64_t mask, uint32_t n_chunks) { return n_chunks <= 1 ? 0u : (uint32_t) ((mask * 0x9E3779B97F4A7C15ull) >> 40) % n_chunks; }
 
 extern "C" int mm_set_profiling(mm_ctx *c, int on) {
   if (!c) return fail(MM_ERR_ARG, "mm_set_profiling: null context");

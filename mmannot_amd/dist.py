@@ -67,11 +67,14 @@ def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], dev
     return mk, out[:len(mk)].astype(np.float64), {k: int(v) for k, v in zip(names, out[len(mk):])}
 
 
-def chain_ratio(counter, stats: Dict[str, int], device=None, group=None):
+def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunks: int = 8):
     """-y ratio across ranks that hold consecutive blocks of the file (rank order = file order).  Every rank has already probed
-    and sorted its batches with defer_ratio; the ordered double accumulation (mmannot.cpp:1730) is then chained: receive the
-    rows of rank-1, seed, replay the parked batches, send the rows to rank+1; the last rank broadcasts the final table.
-    Returns (masks, sums, stats) identical on every rank."""
+    and sorted its batches with defer_ratio; the ordered double accumulation (mmannot.cpp:1730) is then chained - pipelined by
+    row chunks: rows do not depend on each other, so for chunk c = 0..n_chunks-1 a rank receives the chunk's rows from rank-1,
+    seeds them, replays its parked batches for those rows only (mm_ratio_resolve_chunk) and sends them to rank+1 - which works on
+    chunk c while this rank goes on with c+1.  The chain costs (ranks + n_chunks - 1) / n_chunks replays instead of `ranks`.
+    The last rank broadcasts the final table.  Returns (masks, sums, stats) identical on every rank."""
+    from .api import row_chunk
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         counter.resolve_ratio()
         m, s = counter.getCounts()
@@ -95,13 +98,17 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None):
         dist.recv(m, src=src, group=group); dist.recv(s, src=src, group=group)
         return m.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.float64)
 
-    if rank > 0:
-        m, s = recv_rows(rank - 1)
-        counter.set_row_sums(m, s)
-    counter.resolve_ratio()
+    n_chunks = max(1, int(n_chunks))
+    for c in range(n_chunks):
+        if rank > 0:
+            m, s = recv_rows(rank - 1)
+            counter.set_row_sums(m, s)
+        counter.resolve_ratio_chunk(c, n_chunks)
+        if rank < ws - 1:
+            masks, sums = counter.getCounts()
+            sel = row_chunk(masks, n_chunks) == c
+            send_rows(np.ascontiguousarray(masks[sel]), np.ascontiguousarray(sums[sel]), rank + 1)
     masks, sums = counter.getCounts()
-    if rank < ws - 1:
-        send_rows(masks, sums, rank + 1)
     # final table from the last rank to everybody
     n = torch.tensor([len(masks)], dtype=torch.int64, device=dev)
     dist.broadcast(n, src=ws - 1, group=group)

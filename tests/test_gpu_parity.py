@@ -297,7 +297,8 @@ def test_qid_bound_too_small_is_an_error_not_a_fault(gpu_lib):
     ctr.close(); index.close()
 
 
-def test_ratio_chain_across_contexts(gpu_lib, oracle):
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_ratio_chain_across_contexts(gpu_lib, oracle, chunks):
     """Multi-GPU -y ratio in miniature: two contexts hold consecutive blocks of one stream, park their accumulation
     (defer_ratio) and chain the per-row sums; the result must be bit-identical to one context over the whole stream and to
     the CPU oracle."""
@@ -323,10 +324,21 @@ def test_ratio_chain_across_contexts(gpu_lib, oracle):
     for lo, hi in ((cut, 1_700_000), (1_700_000, n)):
         b.add_batch(aln[lo:hi], t["nh"][lo:hi], n); b.sync()
     a.flush(); b.flush()
-    a.resolve_ratio()
-    ma, sa = a.getCounts()
-    b.set_row_sums(ma, sa)
-    b.resolve_ratio()
+    if chunks == 1:
+        a.resolve_ratio()
+        ma, sa = a.getCounts()
+        b.set_row_sums(ma, sa)
+        b.resolve_ratio()
+    else:   # the pipelined chain of mmannot_amd/dist.py in miniature: chunk by chunk (rows are independent of each other)
+        assert sorted(set(mm.row_chunk(np.arange(1, 5000, dtype=np.uint64), chunks).tolist())) == list(range(chunks))
+        from mmannot_amd._lib import lib
+        assert all(lib().mm_row_chunk(int(m), chunks) == int(mm.row_chunk(np.array([m], dtype=np.uint64), chunks)[0]) for m in (1, 2, 3, 1 << 40, 1516545))
+        for c in range(chunks):
+            a.resolve_ratio_chunk(c, chunks)
+            ma, sa = a.getCounts()
+            sel = mm.row_chunk(ma, chunks) == c
+            b.set_row_sums(ma[sel], sa[sel])
+            b.resolve_ratio_chunk(c, chunks)
     mb, sb = b.getCounts()
     sta, stb = a.stats(), b.stats()
     assert {k: sta[k] + stb[k] for k in sta} == ref.stats
