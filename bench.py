@@ -176,7 +176,7 @@ def main():
         ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
         stats = ctr.stats()
         if strategy == "ratio" and world > 1:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
-            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev)
+            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "1")))
         else:
             masks, sums = ctr.getCounts()
             masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)

@@ -820,48 +820,45 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
   if (order && threadIdx.x == 0 && tileBad && ((volatile u32 *) info)[INFO_UNSORTED] == 0) atomicOr(&info[INFO_UNSORTED], 1u);
 }
 
-// One workgroup per digit row: exclusive scan of its row of per-tile counts.  The workgroup that finishes last then turns the
-// row totals into the digits' global bases (and, for the first pass of the name sort, finishes the order check between
-// tiles and publishes the number of pairs) - one launch instead of two on a path made of short kernels.
-__global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ rowTotal, u32 *__restrict__ done,
+// One WAVE per digit row (four rows to a workgroup): exclusive scan of its row of per-tile counts - every lane takes 32 consecutive
+// tiles, all its loads in flight together, then a local scan and one wave scan; no workgroup barrier on the way.  The workgroup that
+// finishes last then turns the row totals into the digits' global bases (and, for the first pass of the name sort, finishes the order
+// check between tiles and publishes the number of pairs) - one launch instead of two on a path made of short kernels.  (Until round 2
+// a workgroup per row: 513 arrivals on the one "done" counter, 33 us for the leaf layout's 513 rows; now 129.)
+__global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nblk, u32 nrows, u32 *__restrict__ rowTotal, u32 *__restrict__ done,
                                                  u32 *__restrict__ info, int shift, int fixed_bits, int order, u64 *__restrict__ walkstat) {
   __shared__ u32 wsum[4];
-  __shared__ u32 carry;
   __shared__ u32 isLast;
   if (shift > 0 && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
-  u32 *row = hist + (size_t) blockIdx.x * nblk;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
   const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // digit rows this pass did not write (its digits are narrower than RS_BINS) total zero; every other row is scanned:
-  // every thread owns 16 consecutive tiles: all its loads are in flight together, then local scan -> wave -> workgroup
-  const bool unused = blockIdx.x < RS_BINS && blockIdx.x >= (1u << batch_layout(info, fixed_bits).width);   // block-uniform
-  for (u32 base = 0; base < nblk && !unused; base += 256 * 16) {
-    const u32 i0 = base + threadIdx.x * 16;
-    u32 v[16];
+  const u32 rowId = blockIdx.x * 4 + w;
+  if (rowId < nrows) {                                    // (wave-uniform)
+    u32 *row = hist + (size_t) rowId * nblk;
+    // digit rows this pass did not write (its digits are narrower than RS_BINS) total zero
+    const bool unused = rowId < RS_BINS && rowId >= (1u << batch_layout(info, fixed_bits).width);
+    u32 carry = 0;
+    for (u32 base = 0; base < nblk && !unused; base += 64 * 32) {
+      const u32 i0 = base + lane * 32;
+      u32 v[32];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
-    u32 tot = 0;
+      for (int k = 0; k < 32; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
+      u32 tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { const u32 t = v[k]; v[k] = tot; tot += t; }
-    u32 x = tot;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 y = __shfl_up(x, off);
-      if ((int) lane >= off) x += y;
+      for (int k = 0; k < 32; ++k) { const u32 t = v[k]; v[k] = tot; tot += t; }
+      u32 x = tot;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off);
+        if ((int) lane >= off) x += y;
+      }
+      const u32 pre = carry + x - tot;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) if (i0 + k < nblk) row[i0 + k] = pre + v[k];
+      carry += (u32) __builtin_amdgcn_readlane((int) x, 63);
     }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    u32 woff = carry;
-    for (u32 k = 0; k < w; ++k) woff += wsum[k];
-    const u32 pre = woff + x - tot;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) if (i0 + k < nblk) row[i0 + k] = pre + v[k];
-    __syncthreads();
-    if (threadIdx.x == 255) carry = pre + tot;
-    __syncthreads();
+    if (lane == 0) rowTotal[rowId] = carry;
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    rowTotal[blockIdx.x] = carry;
     __threadfence();
     isLast = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
   }
@@ -2211,15 +2208,15 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
   hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
-  // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
-  hipLaunchKernelGGL(k_rs_scan, dim3(rebase ? RS_ROW_COUNT + 1 : RS_BINS), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
+  const u32 nrows = rebase ? RS_ROW_COUNT + 1 : RS_BINS;      // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
+  hipLaunchKernelGGL(k_rs_scan, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, c->d_hist, nblk, nrows, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
                      c->d_M, 0, fixed_bits, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
                      fixed_bits, c->d_hist, c->d_rowTot, nblk);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int shift = 8; shift < max_bits; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
-    hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), dim3(256), 0, c->stream, c->d_hist, nblk, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
+    hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS / 4), dim3(256), 0, c->stream, c->d_hist, nblk, (u32) RS_BINS, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
                        fixed_bits, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk);

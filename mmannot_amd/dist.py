@@ -67,13 +67,15 @@ def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], dev
     return mk, out[:len(mk)].astype(np.float64), {k: int(v) for k, v in zip(names, out[len(mk):])}
 
 
-def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunks: int = 8):
+def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunks: int = 1):
     """-y ratio across ranks that hold consecutive blocks of the file (rank order = file order).  Every rank has already probed
-    and sorted its batches with defer_ratio; the ordered double accumulation (mmannot.cpp:1730) is then chained - pipelined by
-    row chunks: rows do not depend on each other, so for chunk c = 0..n_chunks-1 a rank receives the chunk's rows from rank-1,
-    seeds them, replays its parked batches for those rows only (mm_ratio_resolve_chunk) and sends them to rank+1 - which works on
-    chunk c while this rank goes on with c+1.  The chain costs (ranks + n_chunks - 1) / n_chunks replays instead of `ranks`.
-    The last rank broadcasts the final table.  Returns (masks, sums, stats) identical on every rank."""
+    and sorted its batches with defer_ratio; the ordered double accumulation (mmannot.cpp:1730) is then chained: receive the
+    rows of rank-1, seed, replay the parked batches, send the rows to rank+1; the last rank broadcasts the final table.
+    n_chunks > 1 pipelines the chain by row chunks (rows do not depend on each other): for chunk c = 0..n_chunks-1 a rank receives
+    the chunk's rows, replays its parked batches for those rows only (mm_ratio_resolve_chunk) and sends them on - the next rank
+    works on chunk c while this one goes on with c+1, (ranks + n_chunks - 1) / n_chunks replays instead of `ranks`.  Measured
+    (DESIGN.md section 5): with rows travelling through the host on every hop the fixed cost per hop outweighs the overlap, so
+    the default stays 1.  Returns (masks, sums, stats) identical on every rank."""
     from .api import row_chunk
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         counter.resolve_ratio()
