@@ -61,3 +61,16 @@ def test_two_ranks_ratio_chain_gloo(gpu_lib):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and d["table_rows"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_strong_scaling_gloo(gpu_lib):
+    """--scaling strong: the job's K x 2^B tuples are split over the ranks instead of every rank bringing its own."""
+    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20",
+                        "--scaling", "strong"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads(_json_lines(p.stdout.decode())[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["stats"]["nHits"] == 4 * (1 << 20) and d["config"]["batch_alignments_per_gpu"] == 1 << 19
