@@ -255,8 +255,14 @@ def main():
                     traffic = json.load(open(pj)).get(args.workload, {}).get("k_probe_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # whole step against the HBM roof with SURVEY.md 8d's algorithmic bytes: 32 B per alignment (stream in + index probe), 49 B with
+            # the multi-hit merge (-y default, NH > 1: + 16 B mask RMW + 8 B per group)
+            b_step = 49.0 if (strategy == "default" and nh_max > 1) else 32.0
+            step_gbs = job / k_el / world * b_step / 1e9
             out["kernel_only"] = {"value": job / k_el, "unit": "alignments/s", "ms_per_step": k_el / args.steps * 1e3,
-                                  "note": "same batches resident in HBM when the timed region starts (no copy); the roofline leg"}
+                                  "note": "same batches resident in HBM when the timed region starts (no copy); the roofline leg",
+                                  "step_roofline": {"bound": "hbm", "alg_bytes_per_alignment": b_step, "achieved": step_gbs, "peak": 8000.0,
+                                                    "unit": "GB/s", "frac": step_gbs / 8000.0}}
             out["roofline"] = {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
                                "dominant_phase": dom}

@@ -554,6 +554,39 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
   return sel;
 }
 
+// ----------------------------------------------------------------------------- tiles of the grouping pipeline (k_probe fills the first histogram itself when it can)
+#define RS_THREADS 512
+#define RS_NW (RS_THREADS / 64)
+#define RS_ROUNDS 16
+#define RS_TILE (RS_THREADS * RS_ROUNDS)
+
+// ----------------------------------------------------------------------------- stable radix passes (digits of up to 9 bits)
+// First pass (FIRST = true) reads the batch's records where k_probe left them: key gkey[i] (NO_KEY = not in the
+// grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
+// payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
+// in file order within each digit, and k_rs_scan publishes their number (INFO_M) for the following passes.
+// Histogram update of one wave.  Read-name ids spread evenly over the digits and plain LDS atomics are best (the
+// aggregation below costs 6 % of the sort there).  -y ratio sorts by table slot, where a handful of rows take most
+// records: then (skewed) the digit of the first pending lane is counted once for all the lanes that share it, twice,
+// before the rest use atomics - this removes the same-address serialisation SQ_WAIT_INST_LDS showed in these kernels.
+// SH = 0: h holds one u32 counter per digit; SH = 1: two 16-bit counters per u32 (digit d in half d & 1 of word d >> 1;
+// a wave adds at most 1024 per digit and tile, so a half never carries into its neighbour).
+template <int SH>
+__device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewed) {
+  const u32 idx = SH ? (d >> 1) : d, sh = SH ? ((d & 1u) << 4) : 0u;
+  if (!skewed) { if (ok) atomicAdd(&h[idx], 1u << sh); return; }
+  const u32 lane = threadIdx.x & 63;
+  u64 pend = __ballot(ok);
+  for (int it = 0; it < 2 && pend; ++it) {
+    const int l0 = __ffsll((long long) pend) - 1;
+    const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
+    const u64 same = __ballot(ok && d == d0) & pend;
+    if ((int) lane == l0) atomicAdd(&h[idx], (u32) __popcll(same) << sh);
+    pend &= ~same;
+  }
+  if ((pend >> lane) & 1ull) atomicAdd(&h[idx], 1u << sh);
+}
+
 // scan() + getFirst() of one tuple: read strand from -s (strandF / strandR / strandU, mmannot.cpp:836-844), then the index
 template <int OVL>
 __device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, const uint2 *chrSlot, const u64 *sLine, const int4 a, u32 &walked) {
@@ -575,8 +608,12 @@ template <int OVL>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
                                                int single, u32 qlo, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
                                                u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
-                                               u64 *__restrict__ walkstat) {
+                                               u64 *__restrict__ walkstat, u32 *__restrict__ hist, u32 nblk) {
+  // hist != NULL (the host knows that the batch takes the leaf layout, rebased at qlo): one workgroup per RS_TILE tuples, in tile
+  // order, which also counts the tile's multi-hit records per bucket - the partition pass's histogram, without a kernel of its own
+  // re-reading the keys.  The probe waits on gathers most of the time; the LDS adds ride along.
   __shared__ LdsTable T;
+  __shared__ u32 sHist[RS_BINS];
   __shared__ u32 sstat[8];
   __shared__ u32 sq[3];   // max(~qid) = ~min, max(qid), saw NH >= 0xFFFF
   __shared__ u64 sLine[64];          // lineMask and the per-chromosome slot table are read once per alignment:
@@ -587,6 +624,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   lds_table_init(T);
   if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
   if (threadIdx.x < 3) sq[threadIdx.x] = 0;
+  if (hist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) sHist[d] = 0;
   __syncthreads();
   u32 qinv = 0, qmax = 0, bigNh = 0;
   const u32 lane = threadIdx.x & 63;
@@ -594,9 +632,11 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   u32 walked = 0;
   const bool grouped_strategy = (P.strategy == MM_STRAT_DEFAULT);
   const bool ratio = (P.strategy == MM_STRAT_RATIO);
-  for (size_t base = (size_t) blockIdx.x * blockDim.x; base < n; base += (size_t) gridDim.x * blockDim.x) {
+  const size_t first = hist ? (size_t) blockIdx.x * RS_TILE : (size_t) blockIdx.x * blockDim.x;
+  const size_t last = hist ? min(n, first + (size_t) RS_TILE) : n, step = hist ? (size_t) blockDim.x : (size_t) gridDim.x * blockDim.x;
+  for (size_t base = first; base < last; base += step) {
     const size_t i = base + threadIdx.x;
-    const bool valid = i < n;
+    const bool valid = i < last;
     int4 a = make_int4(0, 0, 0, 0);
     u32 nh = 1;
     if (valid) {
@@ -608,18 +648,21 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     u64 mask = 0;
     if (processed) mask = probe_tuple<OVL>(P, chrSlot, sLine, a, walked);
     const int np = __popcll(mask);
-    const bool grouped = processed && grouped_strategy && nh > 1;
+    bool grouped = processed && grouped_strategy && nh > 1;
+    // a multi-hit tuple below the caller's qid_lo: the launches (and, fused, the histogram's origin) were sized on that promise -
+    // the batch is refused, and the tuple stays out of the pipeline so that nothing is written out of bounds
+    if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
     cHits += __popcll(__ballot(processed));
     cUnas += __popcll(__ballot(processed && np == 0));
     cAmb += __popcll(__ballot(processed && np > 1));
     cUnique += __popcll(__ballot(processed && np == 1 && nh == 1));
     cMulti += __popcll(__ballot(grouped));
+    if (hist) wave_hist_add<0>(sHist, min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u), grouped, true);   // (an id outside the promised range is an error anyway)
     cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
     const bool counted = processed && !grouped && mask != 0 && P.strategy != MM_STRAT_RANDOM;   // mmannot.cpp:1704 (random: the caller decides)
     u32 key = NO_KEY, pay = GT_NO_SLOT;
     if (grouped) {
       key = (u32) a.w;
-      if (key < qlo) atomicCAS(G.err, 0u, (u32) ERR_QID_LO);   // the caller's qid_lo hint sized the launches of this batch
       qinv = max(qinv, ~key); qmax = max(qmax, key);
       if (nh >= 0xFFFFu) bigNh = 1;
     }
@@ -658,6 +701,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   }
   __syncthreads();
   if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
+  if (hist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
   if (grouped_strategy && gkey && threadIdx.x == 0) {
     if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
     if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
@@ -688,38 +732,6 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_sets(const ProbePar
 }
 
 // ----------------------------------------------------------------------------- grouping pipeline: tiles of (key, payload) pairs
-#define RS_THREADS 512
-#define RS_NW (RS_THREADS / 64)
-#define RS_ROUNDS 16
-#define RS_TILE (RS_THREADS * RS_ROUNDS)
-
-// ----------------------------------------------------------------------------- stable radix passes (digits of up to 9 bits)
-// First pass (FIRST = true) reads the batch's records where k_probe left them: key gkey[i] (NO_KEY = not in the
-// grouping pipeline) and payload gpay[i], i in file order.  Filtering, key rebasing (qid - qmin) and the choice of the
-// payload happen on the fly, so the ordered compaction costs no pass of its own; the pass leaves the pairs compacted,
-// in file order within each digit, and k_rs_scan publishes their number (INFO_M) for the following passes.
-// Histogram update of one wave.  Read-name ids spread evenly over the digits and plain LDS atomics are best (the
-// aggregation below costs 6 % of the sort there).  -y ratio sorts by table slot, where a handful of rows take most
-// records: then (skewed) the digit of the first pending lane is counted once for all the lanes that share it, twice,
-// before the rest use atomics - this removes the same-address serialisation SQ_WAIT_INST_LDS showed in these kernels.
-// SH = 0: h holds one u32 counter per digit; SH = 1: two 16-bit counters per u32 (digit d in half d & 1 of word d >> 1;
-// a wave adds at most 1024 per digit and tile, so a half never carries into its neighbour).
-template <int SH>
-__device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewed) {
-  const u32 idx = SH ? (d >> 1) : d, sh = SH ? ((d & 1u) << 4) : 0u;
-  if (!skewed) { if (ok) atomicAdd(&h[idx], 1u << sh); return; }
-  const u32 lane = threadIdx.x & 63;
-  u64 pend = __ballot(ok);
-  for (int it = 0; it < 2 && pend; ++it) {
-    const int l0 = __ffsll((long long) pend) - 1;
-    const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
-    const u64 same = __ballot(ok && d == d0) & pend;
-    if ((int) lane == l0) atomicAdd(&h[idx], (u32) __popcll(same) << sh);
-    pend &= ~same;
-  }
-  if ((pend >> lane) & 1ull) atomicAdd(&h[idx], 1u << sh);
-}
-
 template <bool FIRST>
 __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *__restrict__ vin, const u32 *__restrict__ info, size_t i, size_t n,
                                         int rebase, u32 &k, u32 &v) {
@@ -927,7 +939,7 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
                                                            u32 *__restrict__ vout, const u32 *__restrict__ info, size_t n, int rebase, int shift,
-                                                           int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk) {
+                                                           int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk, int forced_leaf) {
   __shared__ u32 lkey[RS_TILE];
   __shared__ u32 lval[RS_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short cntw[RS_NW][RS_BINS];   // A: digit counts per wave; C: running tile-local offset per wave (< 8192)
@@ -936,6 +948,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   __shared__ u32 tcountS;
   if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
   const SortLayout L = batch_layout(info, fixed_bits);
+  // the host took the leaf layout for granted (k_probe counted buckets) but a read-name id lies outside the range it was promised:
+  // the histogram does not fit this layout - write nothing; k_leaf reports the batch
+  if (forced_leaf && !L.leaf) return;
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const size_t lim = FIRST ? n : (size_t) info[INFO_M];
   if (lo >= lim) return;
@@ -1237,13 +1252,14 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8,
   __shared__ u32 sCnt[LEAF_NAMES];   // A: records of the name in this batch;      C: the name's remaining count
   __shared__ u32 sOA[LEAF_NAMES];    // A: AND << 16 | OR of the name's NH values;  C: LEAF_ILL marks the names being replayed
   __shared__ u32 sOpened, sRescued, sIll;
-  const u32 M = info[INFO_M];
-  if (M == 0) return;
   if (!batch_is_leaf(info)) {                            // this batch is k_chunk_default's - unless the host counted on the leaf layout
-    // (forced: the caller's qid_lo / qid_bound promised a key range of at most 21 bits and only this kernel was launched)
+    // (forced: the caller's qid_lo / qid_bound promised a key range of at most 21 bits, only this kernel was launched and the
+    // histogram was made for that layout; a wider range means some read-name id lies outside the promise)
     if (forced && threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND);
     return;
   }
+  const u32 M = info[INFO_M];
+  if (M == 0) return;
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
   if ((u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
   const u32 qmin = ~info[INFO_QINV];
@@ -1270,13 +1286,14 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     for (u32 i = t; i < LEAF_NAMES; i += LEAF_THREADS) { sU[i] = 0; sCnt[i] = 0; sOA[i] = 0xFFFF0000u; }
     if (t == 0) sIll = 0;
     __syncthreads();
-    // ---- A: one streaming pass, four records per lane in flight
-    for (u64 i0 = (u64) lo + t; i0 < hi; i0 += 4 * LEAF_THREADS) {
-      u64 r[4];
+    // ---- A: one streaming pass, eight records per lane in flight (a bucket is ~40 K records: five round trips to memory)
+#define LEAF_UNROLL 8
+    for (u64 i0 = (u64) lo + t; i0 < hi; i0 += LEAF_UNROLL * LEAF_THREADS) {
+      u64 r[LEAF_UNROLL];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const u64 i = i0 + (u64) k * LEAF_THREADS; r[k] = (i < hi) ? recs[i] : ~0ull; }
+      for (int k = 0; k < LEAF_UNROLL; ++k) { const u64 i = i0 + (u64) k * LEAF_THREADS; r[k] = (i < hi) ? recs[i] : ~0ull; }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < LEAF_UNROLL; ++k) {
         if (i0 + (u64) k * LEAF_THREADS < hi) {
           const u32 loc = (u32) (r[k] >> 32) & (LEAF_NAMES - 1u);
           atomicAdd(&sCnt[loc], 1u);
@@ -1290,6 +1307,7 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
       }
     }
+#undef LEAF_UNROLL
     __syncthreads();
     // ---- B: closed form per name
     const u32 q0 = qmin + (b << LEAF_BITS);
@@ -2204,22 +2222,24 @@ static int bits_for(u64 bound) {
 // Stable LSD sort of the batch's pairs (kA,vA) on the low `max_bits` key bits.  The passes the batch's actual key
 // range does not need return immediately (device-side decision, no host round trip); the consumer works out from
 // the same device scalars whether the result sits in A or B.
-static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int rebase) {
+static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int rebase, bool have_hist = false) {
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
-  hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
-  const u32 nrows = rebase ? RS_ROW_COUNT + 1 : RS_BINS;      // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
+  // (have_hist: k_probe has counted the tiles' buckets itself - leaf layout taken for granted, no order check, no count row)
+  if (!have_hist)
+    hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
+  const u32 nrows = (rebase && !have_hist) ? RS_ROW_COUNT + 1 : RS_BINS;      // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
   hipLaunchKernelGGL(k_rs_scan, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, c->d_hist, nblk, nrows, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
                      c->d_M, 0, fixed_bits, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
-                     fixed_bits, c->d_hist, c->d_rowTot, nblk);
+                     fixed_bits, c->d_hist, c->d_rowTot, nblk, have_hist ? 1 : 0);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int shift = 8; shift < max_bits; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
     hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS / 4), dim3(256), 0, c->stream, c->d_hist, nblk, (u32) RS_BINS, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
                        fixed_bits, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
-                       c->d_hist, c->d_rowTot, nblk);
+                       c->d_hist, c->d_rowTot, nblk, 0);
     std::swap(kin, kout); std::swap(vin, vout);
   }
   HIPCHK(hipGetLastError());
@@ -2326,23 +2346,25 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   fill_params(c, P);
   const bool need_groups = (dflt && !single) || ratio;
   const u32 grid = (u32) std::min<size_t>((n + 255) / 256, 256 * 8);
+  const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   u64 *hm = c->d_hm;
   u32 *gkey = need_groups ? c->d_gkey : nullptr;
   // host-known key range of this batch's multi-hit records: within the leaf layout's reach?  Then that path is taken for granted
   const int span_bits = dflt ? bits_for((qid_bound ? qid_bound : 1) - qid_lo) : 16;
   const bool force_leaf = dflt && need_groups && span_bits <= LEAF_BITS + LEAF_DIGIT_BITS;
+  const bool fuse_hist = force_leaf && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
   PhaseTimer t(c, MM_PHASE_PROBE);
   switch (c->opt.overlap_mode) {
     case MM_OVL_INCLUSION:
-      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
       break;
     case MM_OVL_PC:
-      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
       break;
     default:
-      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk);
+      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
   }
   }
   bool huge_nh = false;                                  // an NH >= 65535 can only come through the side list
@@ -2367,7 +2389,7 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       PhaseTimer t(c, MM_PHASE_SORT);
       // passes to launch: from the widest key range this batch can have (the kernels of a pass the actual range does not need
       // return at once); within LEAF_BITS + LEAF_DIGIT_BITS bits the one partition pass of the leaf layout is all there is
-      rc = sort_pairs(c, n, force_leaf ? 8 : span_bits, dflt ? 0 : 16, dflt ? 1 : 0);
+      rc = sort_pairs(c, n, force_leaf ? 8 : span_bits, dflt ? 0 : 16, dflt ? 1 : 0, fuse_hist);
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);

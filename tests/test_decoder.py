@@ -114,3 +114,31 @@ def test_fast_record_path_equals_general_parser(oracle, tmp_path, monkeypatch):
         gen = _decode(path, an)
         assert (fast[0] == gen[0]).all() and (fast[1] == gen[1]).all(), label
         assert fast[2:] == gen[2:], label
+
+
+def test_header_larger_than_a_batch_and_cut_records(oracle, tmp_path):
+    """The BGZF pipe frames and parses records on its threads only when the BAM header lies inside the first batch of blocks
+    (512 x 64 KiB); a longer header text leaves the whole file to the sequential reader.  And with tiny blocks nearly every record
+    is cut by a block boundary and many by a batch boundary (the tail moves to the front of the next batch).  Same tuples, names and
+    messages as the same payload stored as one gzip member, both ways."""
+    import struct
+    import mmannot_amd.api as api
+    kat = os.path.join(gu.GOLD, "kat", "X1_xa")
+    an = api.Annotation(os.path.join(kat, "c.cfg"), os.path.join(kat, "a.gtf"))
+    rng = np.random.default_rng(8)
+    n = 30000
+    chroms = [("chr1", 100000), ("chrZ", 50000)]
+    body = oracle.bam_records_fixed(rng.integers(-1, 2, n), rng.integers(0, 90000, n), rng.integers(0, 32, n).astype(np.uint16) & 16,
+                                    rng.integers(0, 7000, n), rng.integers(20, 150, n), rng.integers(0, 9, n).astype(np.uint32))
+    refs = b"".join(struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln) for nm, ln in chroms)
+    for text_len, block in ((0, 61), (34 << 20, 0xff00)):
+        text = (b"@CO\t" + b"x" * 59 + b"\n") * (text_len // 64)
+        payload = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(chroms)) + refs + body
+        pg, pb = str(tmp_path / f"g{block}.bam"), str(tmp_path / f"b{block}.bam")
+        with gzip.open(pg, "wb", compresslevel=1) as f:
+            f.write(payload)
+        oracle.write_bgzf(pb, payload, level=1, block=block)
+        a = _decode(pg, an)
+        b = _decode(pb, an, cap=4099)
+        assert len(a[0]) == n and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        assert a[2:] == b[2:]

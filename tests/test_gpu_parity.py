@@ -195,6 +195,22 @@ def test_nh_side_list_errors(gpu_lib):
     ctr.add_batch(mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n), np.full(n, 2)), None, n, single_hit=True)
     with pytest.raises(mm.MMError):                 # promise broken: NH = 2 everywhere
         ctr.sync()
+    ctr.close()
+    two = mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n) + 1000, np.full(n, 2))
+    ctr = mm.Counter(index)
+    ctr.add_batch(two, None, 1000 + n, qid_lo=1000)   # the hint holds: fine (and the host takes the leaf layout for granted)
+    ctr.sync(); ctr.close()
+    ctr = mm.Counter(index)
+    ctr.add_batch(two, None, 1000 + n, qid_lo=1050)   # 50 multi-hit tuples below the promised lower bound
+    with pytest.raises(mm.MMError):
+        ctr.sync()
+    ctr.close()
+    ctr = mm.Counter(index)
+    wide = mm.pack_alignments(np.zeros(n), np.full(n, 100), np.full(n, 150), np.ones(n), np.arange(n) * 40000, np.full(n, 2))
+    ctr.reserve(n * 40000 + 1)
+    ctr.add_batch(wide, None, 2000, qid_lo=0)          # ids far beyond the bound the launches were sized for: refused, not miscounted
+    with pytest.raises(mm.MMError):
+        ctr.sync()
     ctr.close(); index.close()
 
 
