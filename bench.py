@@ -128,17 +128,32 @@ def main():
         _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), B, C.byref(p), stream))
         alns.append(a)
     torch.cuda.synchronize()
-    groups_per_tuple = (nh_max / (nh_max * (nh_max + 1) / 2.0)) if nh_max > 1 else 1.0
-    qb = int(nb * B * groups_per_tuple) + nh_max + 2   # exclusive bound of the read-name ids of the whole stream (a larger bound is allowed)
+    # exclusive bound of the read-name ids of the whole stream (names are numbered along the logical order of the hits; the scatter
+    # permutes inside windows of 2^scatter tuples, so ids reach to the end of the last window touched)
+    if nh_max > 1:
+        last_l = -((-nb * B) // (1 << scatter)) * (1 << scatter)
+        qb = (last_l // (nh_max * (nh_max + 1) // 2) + 2) * nh_max + 2
+    else:
+        qb = nb * B + 2
     total_tuples = world * nb * B
 
-    def qlo(step):   # smallest read-name id a multi-hit tuple of this batch can have (the decoder of a real input knows it too)
+    # Read-name ids of a batch: the decoder of a real input knows the smallest id among a batch's multi-hit tuples and the size of its
+    # dictionary; here both follow from the generator.  The hits of a read are spread over windows of 2^scatter tuples: inside the batch
+    # (the default), or - a window wider than a batch, e.g. --scatter-log2 28 - over many batches, which is what a coordinate-sorted
+    # file looks like (every batch then touches the names of a whole window: a wide key range, several partition passes).
+    T_grp = nh_max * (nh_max + 1) // 2
+    W_sc = 1 << scatter
+
+    def qlo(step):
         if nh_max <= 1:
             return 0
-        return (step * B // (nh_max * (nh_max + 1) // 2)) * nh_max
+        return ((step * B // W_sc) * W_sc // T_grp) * nh_max
 
-    def qbound(step):   # exclusive bound of the read-name ids seen up to and including this batch (what a decoder reports: its dictionary's size)
-        return min(qb, qlo(step + 1) + 2 * nh_max + 2)
+    def qbound(step):   # exclusive bound of the ids seen up to and including this batch
+        if nh_max <= 1:
+            return qb
+        hi = -((-(step + 1) * B) // W_sc) * W_sc
+        return min(qb, (hi // T_grp + 2) * nh_max + 2)
     if nh_max > 1 and strategy == "default":
         ctr.reserve(qb)         # the per-read-name state is sized once, before any timing (a decoder that knows the number of reads)
 

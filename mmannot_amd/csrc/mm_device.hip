@@ -94,35 +94,42 @@ enum { INFO_M = 0,      // number of records in the grouping pipeline
        INFO_QMAX = 2,   // largest qid of the multi-hit records
        INFO_BIGNH = 3,  // some multi-hit record has NH >= 65535: payloads carry the record index instead of (slot, NH)
        INFO_UNSORTED = 4,  // the multi-hit records' qids are not already non-decreasing in file order (name-grouped input is)
-       INFO_WORDS = 5 };
+       INFO_NLIST = 5,  // number of non-empty buckets listed by k_bucket_bounds (leaf layout with more than one partition pass)
+       INFO_WORDS = 6 };
 
 __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits needed for keys in [0, span]
   int b = 1;
   while (b < 32 && (1ull << b) <= (unsigned long long) span) ++b;
   return b;
 }
-// Grouping layout of this batch.  Multi-hit records are keyed by qid - qmin (fixed 16 bits for -y ratio's slot keys).
-//   * "leaf" layout (the key range fits LEAF_BITS + LEAF_DIGIT_BITS bits - a 2^24-tuple batch of reads with ~10 hits each
-//     spans 21): ONE stable partition pass on the key's top bits, the "bucket" (key >> LEAF_BITS, up to 512 buckets); k_leaf
-//     then reduces each bucket's 4096 consecutive read names in LDS.  No full sort, no per-name gathers from HBM.
-//   * otherwise a full LSD sort, k_chunk_default behind it: the key's bits are split evenly over the passes an 8-bit layout
-//     would need - 24 bits are sorted as 3 x 8, 26 as 4 x 7 (fewer digits per pass mean longer runs per digit inside a tile,
-//     i.e. longer contiguous segments in the scatter's writes).
+// Grouping layout of this batch.
+//   * -y default ("leaf" layout): the multi-hit records, keyed by qid - qmin, are brought together by *bucket* = key >> LEAF_BITS
+//     (4096 consecutive read names) with stable partition passes over the bucket id, 9 bits or fewer at a time, lowest digit first:
+//     ONE pass when the key range fits LEAF_BITS + 9 = 21 bits (a 2^24-tuple batch of reads with ~10 hits each spans 21), two up
+//     to 30 bits, three beyond.  k_leaf then reduces each bucket's names in LDS.  The low LEAF_BITS of the key are never sorted
+//     on, and no per-name state is gathered from HBM.
+//   * -y ratio sorts its (table row, NH) pairs on a fixed 16 bits: two 8-bit LSD passes.
 #define LEAF_BITS 12
 #define LEAF_NAMES (1u << LEAF_BITS)
 #define LEAF_DIGIT_BITS 9
 #define RS_BINS (1u << LEAF_DIGIT_BITS)   // digit rows of the per-tile histograms (a pass uses the first 2^width of them)
 struct SortLayout { int passes; u32 width; u32 shift0; bool leaf; };
+__host__ __device__ inline SortLayout leaf_layout(int key_bits) {
+  const int bb = key_bits > LEAF_BITS ? key_bits - LEAF_BITS : 1;    // bits of the bucket id
+  SortLayout L;
+  L.passes = (bb + LEAF_DIGIT_BITS - 1) / LEAF_DIGIT_BITS;
+  L.width = (u32) ((bb + L.passes - 1) / L.passes);
+  L.shift0 = LEAF_BITS; L.leaf = true;
+  return L;
+}
 __device__ __forceinline__ SortLayout batch_layout(const unsigned int *info, int fixed_bits) {
-  int bits = fixed_bits;
-  if (!bits) {
+  if (!fixed_bits) {
     const unsigned int qmin = ~info[INFO_QINV], qmax = info[INFO_QMAX];
-    bits = qmax >= qmin ? bits_for_range(qmax - qmin) : 1;
+    return leaf_layout(qmax >= qmin ? bits_for_range(qmax - qmin) : 1);
   }
   SortLayout L;
-  if (!fixed_bits && bits <= LEAF_BITS + LEAF_DIGIT_BITS) { L.passes = 1; L.width = LEAF_DIGIT_BITS; L.shift0 = LEAF_BITS; L.leaf = true; return L; }
-  L.passes = (bits + 7) / 8;
-  L.width = (u32) ((bits + L.passes - 1) / L.passes);
+  L.passes = (fixed_bits + 7) / 8;
+  L.width = (u32) ((fixed_bits + L.passes - 1) / L.passes);
   L.shift0 = 0; L.leaf = false;
   return L;
 }
@@ -131,8 +138,8 @@ __device__ __forceinline__ int batch_passes(const unsigned int *info, int fixed_
   if (!fixed_bits && !info[INFO_UNSORTED]) return 1;
   return batch_layout(info, fixed_bits).passes;
 }
-// is this batch reduced by k_leaf (else: by k_chunk_default, behind the full sort or - name-grouped input - the compaction)
-__device__ __forceinline__ bool batch_is_leaf(const unsigned int *info) { return info[INFO_UNSORTED] != 0 && batch_layout(info, 0).leaf; }
+// is this batch reduced by k_leaf (else - name-grouped input - by k_chunk_default behind the plain compaction)
+__device__ __forceinline__ bool batch_is_leaf(const unsigned int *info) { return info[INFO_UNSORTED] != 0; }
 // digit of key k in the pass the host launched with shift = 8 * pass
 __device__ __forceinline__ u32 batch_digit(u32 k, const SortLayout L, int shift) { return (k >> (L.shift0 + (u32) (shift >> 3) * L.width)) & ((1u << L.width) - 1u); }
 
@@ -744,7 +751,8 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
     return true;
   }
   if (i >= info[INFO_M]) return false;
-  k = kin[i]; v = vin[i];
+  if (rebase) { const u64 r = ((const u64 *) kin)[i]; k = (u32) (r >> 32); v = (u32) r; }   // (leaf layout: 8-byte pairs between the passes)
+  else { k = kin[i]; v = vin[i]; }
   return true;
 }
 
@@ -948,16 +956,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   __shared__ u32 tcountS;
   if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;
   const SortLayout L = batch_layout(info, fixed_bits);
-  // the host took the leaf layout for granted (k_probe counted buckets) but a read-name id lies outside the range it was promised:
-  // the histogram does not fit this layout - write nothing; k_leaf reports the batch
-  if (forced_leaf && !L.leaf) return;
+  // the host took the one-pass leaf layout for granted (k_probe counted buckets) but a read-name id lies outside the range it was
+  // promised: the histogram does not fit this layout - write nothing; k_leaf reports the batch
+  if (forced_leaf && L.passes != 1) return;
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const size_t lim = FIRST ? n : (size_t) info[INFO_M];
   if (lo >= lim) return;
   // name-grouped input (see k_rs_hist): one "digit" for everything, i.e. a stable compaction in file order
   const bool presorted = FIRST && rebase && !info[INFO_UNSORTED];
   const u32 dmask = presorted ? 0u : (RS_BINS - 1u);   // (presorted: every pair in "digit" 0)
-  const bool pairs64 = FIRST && rebase && !presorted && L.leaf;   // output format of the leaf layout's partition pass
+  const bool pairs64 = rebase && !presorted;                      // the leaf layout's partition passes write 8-byte pairs
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   for (u32 q = 0; q < RS_NW; ++q) cntw[q][t] = 0;
   __syncthreads();
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     const u32 d = batch_digit(kreg[r], L, shift) & dmask;
     u64 peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < LEAF_DIGIT_BITS; ++b) {
+    for (int b = 0; b < LEAF_DIGIT_BITS; ++b) {   // (skipping these when the wave's digits are all equal was measured: no gain)
       const u64 bb = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bb : ~bb;
     }
@@ -1229,6 +1237,26 @@ __global__ void k_set_info(u32 *__restrict__ info, u32 qinv, u32 unsorted) {
   if (threadIdx.x < INFO_WORDS) info[threadIdx.x] = threadIdx.x == INFO_QINV ? qinv : (threadIdx.x == INFO_UNSORTED ? unsorted : 0u);
 }
 
+// Leaf layout with more than one partition pass: the records are sorted by bucket now, but where a bucket starts is not a by-product
+// of one pass's digit bases any more.  One streaming pass finds every non-empty bucket's range and lists the buckets for k_leaf
+// (the list is unordered - buckets do not depend on each other).
+__global__ __launch_bounds__(256) void k_bucket_bounds(const u64 *__restrict__ recsA, const u64 *__restrict__ recsB, u32 *__restrict__ info,
+                                                       u32 *__restrict__ bLo, u32 *__restrict__ bHi, u32 *__restrict__ list, u64 nbcap, u32 *__restrict__ err) {
+  if (!batch_is_leaf(info)) return;
+  const SortLayout L = batch_layout(info, 0);
+  if (L.passes < 2) return;
+  const u64 *__restrict__ recs = (L.passes & 1) ? recsB : recsA;      // the passes ping-pong A <- B <- A ...; the first one writes B
+  const u32 M = info[INFO_M];
+  if ((u64) ((info[INFO_QMAX] - ~info[INFO_QINV]) >> LEAF_BITS) >= nbcap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicCAS(err, 0u, (u32) ERR_QID_BOUND); return; }
+  for (size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t) gridDim.x * blockDim.x) {
+    const u32 b = (u32) (recs[j] >> (32 + LEAF_BITS));
+    const bool first = j == 0 || (u32) (recs[j - 1] >> (32 + LEAF_BITS)) != b;
+    const bool last = j + 1 == M || (u32) (recs[j + 1] >> (32 + LEAF_BITS)) != b;
+    if (first) { bLo[b] = (u32) j; list[atomicAdd(&info[INFO_NLIST], 1u)] = b; }
+    if (last) bHi[b] = (u32) j + 1;
+  }
+}
+
 // ----------------------------------------------------------------------------- k_leaf: multi-hit countdown / union per bucket, in LDS
 // "Leaf" layout (see batch_layout): the partition pass has brought the batch's multi-hit records together by bucket = 4096
 // consecutive read names, file order kept inside a bucket.  One workgroup takes a bucket:
@@ -1244,7 +1272,8 @@ __global__ void k_set_info(u32 *__restrict__ info, u32 qinv, u32 unsorted) {
 #define LEAF_THREADS 1024
 #define LEAF_ILL 0xFFFFFFFFu   // sOA value marking an order-dependent name (no OR/AND pair of 16-bit NH values looks like this)
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_leaf(
-    const u64 *__restrict__ recs, const u32 *__restrict__ info, const u32 *__restrict__ base, const int4 *__restrict__ aln,
+    const u64 *__restrict__ recsA, const u64 *__restrict__ recsB, const u32 *__restrict__ info, const u32 *__restrict__ base, const u32 *__restrict__ bLo,
+    const u32 *__restrict__ bHi, const u32 *__restrict__ list, const int4 *__restrict__ aln,
     const uint2 *__restrict__ big, u32 nbig, const u64 *__restrict__ hm, u32 *__restrict__ grpRem, u64 *__restrict__ grpU, u64 qcap,
     GlobalTable G, u64 *__restrict__ stats, int forced) {
   __shared__ LdsTable T;
@@ -1252,18 +1281,19 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8,
   __shared__ u32 sCnt[LEAF_NAMES];   // A: records of the name in this batch;      C: the name's remaining count
   __shared__ u32 sOA[LEAF_NAMES];    // A: AND << 16 | OR of the name's NH values;  C: LEAF_ILL marks the names being replayed
   __shared__ u32 sOpened, sRescued, sIll;
-  if (!batch_is_leaf(info)) {                            // this batch is k_chunk_default's - unless the host counted on the leaf layout
-    // (forced: the caller's qid_lo / qid_bound promised a key range of at most 21 bits, only this kernel was launched and the
-    // histogram was made for that layout; a wider range means some read-name id lies outside the promise)
-    if (forced && threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND);
-    return;
-  }
+  if (!batch_is_leaf(info)) return;                      // name-grouped input: k_chunk_default's
+  const SortLayout L = batch_layout(info, 0);
+  // (forced: the caller's qid_lo / qid_bound promised a key range of at most 21 bits, the launches and k_probe's histogram were made
+  // for ONE partition pass; a wider range means some read-name id lies outside the promise)
+  if (forced && L.passes != 1) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
   const u32 M = info[INFO_M];
   if (M == 0) return;
+  const bool listed = L.passes > 1;                      // buckets from k_bucket_bounds' list; else bucket = digit of the one pass
+  const u64 *__restrict__ recs = (L.passes & 1) ? recsB : recsA;
   // a read-name id at or beyond the caller's qid_bound would index the per-name state out of bounds: refuse the batch
   if ((u64) info[INFO_QMAX] >= qcap) { if (threadIdx.x == 0) atomicCAS(G.err, 0u, (u32) ERR_QID_BOUND); return; }
   const u32 qmin = ~info[INFO_QINV];
-  const u32 nbk = ((info[INFO_QMAX] - qmin) >> LEAF_BITS) + 1u;      // <= RS_BINS by the layout's definition
+  const u32 nbk = listed ? info[INFO_NLIST] : ((info[INFO_QMAX] - qmin) >> LEAF_BITS) + 1u;      // (one pass: <= RS_BINS by the layout's definition)
   const bool by_index = info[INFO_BIGNH] != 0;
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   lds_table_init(T);
@@ -1279,34 +1309,61 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(8,
       if ((U & (U - 1)) == 0) ++rescued;
     }
   };
-  for (u32 b = blockIdx.x; b < nbk; b += gridDim.x) {    // (workgroup-uniform)
-    const u32 lo = base[b], hi = (b + 1 < RS_BINS) ? base[b + 1] : M;
+  for (u32 bi = blockIdx.x; bi < nbk; bi += gridDim.x) {    // (workgroup-uniform)
+    const u32 b = listed ? list[bi] : bi;
+    const u32 lo = listed ? bLo[b] : base[b], hi = listed ? bHi[b] : ((b + 1 < RS_BINS) ? base[b + 1] : M);
     __syncthreads();                                     // the previous bucket's LDS state is no longer read
     if (hi <= lo) continue;
     for (u32 i = t; i < LEAF_NAMES; i += LEAF_THREADS) { sU[i] = 0; sCnt[i] = 0; sOA[i] = 0xFFFF0000u; }
     if (t == 0) sIll = 0;
     __syncthreads();
-    // ---- A: one streaming pass, eight records per lane in flight (a bucket is ~40 K records: five round trips to memory)
-#define LEAF_UNROLL 8
-    for (u64 i0 = (u64) lo + t; i0 < hi; i0 += LEAF_UNROLL * LEAF_THREADS) {
+    // ---- A: one streaming pass, four records per lane in flight (a bucket is ~40 K records: ten round trips to memory).
+    // Consecutive lanes hold consecutive records.  Where an aligner's output keeps the hits of a read together, they also hold the
+    // same name, and 64 lanes would queue on a handful of LDS words: such a wave first reduces each run of equal names towards its
+    // last lane (segmented Kogge-Stone scan on DPP moves, vector ALU only - the network of k_chunk_default) and only that lane goes
+    // to LDS.  A wave without two equal neighbours skips the scan.
+#define LEAF_UNROLL 4
+#define MM_DPP(OLD, SRC, CTRL, RMASK) ((u32) __builtin_amdgcn_update_dpp((int) (OLD), (int) (SRC), (CTRL), (RMASK), 0xF, false))
+    for (u64 i0w = (u64) lo + (t - lane); i0w < hi; i0w += LEAF_UNROLL * LEAF_THREADS) {   // (wave-uniform trip count)
+      const u64 i0 = i0w + lane;
       u64 r[LEAF_UNROLL];
 #pragma unroll
       for (int k = 0; k < LEAF_UNROLL; ++k) { const u64 i = i0 + (u64) k * LEAF_THREADS; r[k] = (i < hi) ? recs[i] : ~0ull; }
 #pragma unroll
       for (int k = 0; k < LEAF_UNROLL; ++k) {
-        if (i0 + (u64) k * LEAF_THREADS < hi) {
-          const u32 loc = (u32) (r[k] >> 32) & (LEAF_NAMES - 1u);
-          atomicAdd(&sCnt[loc], 1u);
-          if (!by_index) {                                // (by index: every name is replayed, the reduction is not used)
-            u64 m; u32 nhv;
-            decode((u32) r[k], m, nhv);
-            if (m) atomicOr(&sU[loc], m);
-            atomicOr(&sOA[loc], nhv);                     // OR in the low half (NH < 65535 here) ...
-            atomicAnd(&sOA[loc], (nhv << 16) | 0xFFFFu);  // ... AND in the high half
+        const bool valid = i0 + (u64) k * LEAF_THREADS < hi;
+        const u32 loc = valid ? ((u32) (r[k] >> 32) & (LEAF_NAMES - 1u)) : (0x40000000u | lane);   // (no two invalid lanes look alike)
+        u64 m = 0;
+        u32 nhv = 0;
+        if (valid && !by_index) decode((u32) r[k], m, nhv);   // (by index: every name is replayed, only the count is used)
+        u32 ulo = (u32) m, uhi = (u32) (m >> 32), cnt = valid ? 1u : 0u, nor = valid ? nhv : 0u, nand = valid ? nhv : 0xFFFFu;
+        const u32 ploc = __shfl_up(loc, 1), nloc = __shfl_down(loc, 1);
+        u32 f = (lane == 0 || ploc != loc) ? 1u : 0u;       // a run starts here
+        if (__ballot(f == 0u)) {                             // (wave-uniform) some lane continues its neighbour's name
+#define MM_SEG_STEP(CTRL, RMASK)                                                                               \
+          {                                                                                                    \
+            const u32 sf = MM_DPP(f, f, CTRL, RMASK); /* a lane without a source keeps its own flag and gets identities */ \
+            const u32 a0 = MM_DPP(0u, ulo, CTRL, RMASK), a1 = MM_DPP(0u, uhi, CTRL, RMASK), ac = MM_DPP(0u, cnt, CTRL, RMASK); \
+            const u32 ao = MM_DPP(0u, nor, CTRL, RMASK), aa = MM_DPP(0xFFFFu, nand, CTRL, RMASK);             \
+            if (!f) { ulo |= a0; uhi |= a1; cnt += ac; nor |= ao; nand &= aa; f = sf; }                       \
+          }
+          MM_SEG_STEP(0x111, 0xF) MM_SEG_STEP(0x112, 0xF) MM_SEG_STEP(0x114, 0xF) MM_SEG_STEP(0x118, 0xF)   // row_shr:1,2,4,8
+          MM_SEG_STEP(0x142, 0xA)                                                                            // row_bcast:15 -> rows 1, 3
+          MM_SEG_STEP(0x143, 0xC)                                                                            // row_bcast:31 -> rows 2, 3
+#undef MM_SEG_STEP
+        }
+        if (valid && (lane == 63 || nloc != loc)) {          // the last lane of a run holds the run's reduction
+          atomicAdd(&sCnt[loc], cnt);
+          if (!by_index) {
+            const u64 um = ((u64) uhi << 32) | ulo;
+            if (um) atomicOr(&sU[loc], um);
+            atomicOr(&sOA[loc], nor);                        // OR in the low half (NH < 65535 here) ...
+            atomicAnd(&sOA[loc], (nand << 16) | 0xFFFFu);    // ... AND in the high half
           }
         }
       }
     }
+#undef MM_DPP
 #undef LEAF_UNROLL
     __syncthreads();
     // ---- B: closed form per name
@@ -1820,6 +1877,8 @@ struct mm_ctx {
   u64 qcap = 0;
   u32 *d_grpRem = nullptr;
   u64 *d_grpU = nullptr;
+  u32 *d_bLo = nullptr, *d_bHi = nullptr, *d_bList = nullptr;   // per bucket of 4096 names: record range of the batch, and the non-empty buckets
+  u64 nbcap = 0;
   // -y ratio with defer_ratio: each batch's slot-sorted (slot, NH) pairs are parked here until mm_ratio_resolve
   struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr, *seg = nullptr; size_t n = 0; };
   std::vector<Run> runs;
@@ -2123,6 +2182,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
+  (void) hipFree(c->d_bLo); (void) hipFree(c->d_bHi); (void) hipFree(c->d_bList);
   for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_big[b]); (void) hipHostFree(c->h_big[b]); if (c->ev_big[b]) (void) hipEventDestroy(c->ev_big[b]); }
   if (c->copy_stream) {
     (void) hipStreamSynchronize(c->copy_stream);
@@ -2197,6 +2257,9 @@ static int ensure_qids(mm_ctx *c, u64 qid_bound) {
   HIPCHK(hipStreamSynchronize(c->stream));
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
   c->d_grpRem = nr; c->d_grpU = nu; c->qcap = ncap;
+  (void) hipFree(c->d_bLo); (void) hipFree(c->d_bHi); (void) hipFree(c->d_bList);
+  c->nbcap = (ncap >> LEAF_BITS) + 2;
+  HIPCHK(hipMalloc((void **) &c->d_bLo, c->nbcap * 4)); HIPCHK(hipMalloc((void **) &c->d_bHi, c->nbcap * 4)); HIPCHK(hipMalloc((void **) &c->d_bList, c->nbcap * 4));
   return MM_OK;
 }
 
@@ -2219,13 +2282,14 @@ static int bits_for(u64 bound) {
   return b;
 }
 
-// Stable LSD sort of the batch's pairs (kA,vA) on the low `max_bits` key bits.  The passes the batch's actual key
-// range does not need return immediately (device-side decision, no host round trip); the consumer works out from
-// the same device scalars whether the result sits in A or B.
-static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int rebase, bool have_hist = false) {
+// The stable passes over the batch's (key, payload) pairs: `passes` of them are launched; those the batch's actual key range does
+// not need return immediately (device-side decision, no host round trip) and the consumer works out from the same device
+// scalars whether the result sits in A or B.  rebase = 1: -y default (keys qid - qmin, leaf layout: 8-byte pairs between the
+// passes); 0: -y ratio's fixed 16 key bits.
+static int sort_pairs(mm_ctx *c, size_t n, int passes, int fixed_bits, int rebase, bool have_hist = false) {
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
-  // (have_hist: k_probe has counted the tiles' buckets itself - leaf layout taken for granted, no order check, no count row)
+  // (have_hist: k_probe has counted the tiles' buckets itself - one-pass leaf layout taken for granted, no order check, no count row)
   if (!have_hist)
     hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
   const u32 nrows = (rebase && !have_hist) ? RS_ROW_COUNT + 1 : RS_BINS;      // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
@@ -2234,11 +2298,12 @@ static int sort_pairs(mm_ctx *c, size_t n, int max_bits, int fixed_bits, int reb
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
                      fixed_bits, c->d_hist, c->d_rowTot, nblk, have_hist ? 1 : 0);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
-  for (int shift = 8; shift < max_bits; shift += 8) {
-    hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, 0, shift, fixed_bits, c->d_hist, nblk);
+  for (int pass = 1; pass < passes; ++pass) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, rebase, shift, fixed_bits, c->d_hist, nblk);
     hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS / 4), dim3(256), 0, c->stream, c->d_hist, nblk, (u32) RS_BINS, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
                        fixed_bits, 0, c->d_walk);
-    hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, 0, shift, fixed_bits,
+    hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, rebase, shift, fixed_bits,
                        c->d_hist, c->d_rowTot, nblk, 0);
     std::swap(kin, kout); std::swap(vin, vout);
   }
@@ -2349,9 +2414,11 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   u64 *hm = c->d_hm;
   u32 *gkey = need_groups ? c->d_gkey : nullptr;
-  // host-known key range of this batch's multi-hit records: within the leaf layout's reach?  Then that path is taken for granted
+  // host-known key range of this batch's multi-hit records -> partition passes to launch (the device may need fewer).  One pass: that
+  // layout is taken for granted (no order check, k_probe counts the buckets itself)
   const int span_bits = dflt ? bits_for((qid_bound ? qid_bound : 1) - qid_lo) : 16;
-  const bool force_leaf = dflt && need_groups && span_bits <= LEAF_BITS + LEAF_DIGIT_BITS;
+  const int n_passes = dflt ? leaf_layout(span_bits).passes : 2;
+  const bool force_leaf = dflt && need_groups && n_passes == 1;
   const bool fuse_hist = force_leaf && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
@@ -2387,17 +2454,20 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   if (need_groups) {
     {
       PhaseTimer t(c, MM_PHASE_SORT);
-      // passes to launch: from the widest key range this batch can have (the kernels of a pass the actual range does not need
-      // return at once); within LEAF_BITS + LEAF_DIGIT_BITS bits the one partition pass of the leaf layout is all there is
-      rc = sort_pairs(c, n, force_leaf ? 8 : span_bits, dflt ? 0 : 16, dflt ? 1 : 0, fuse_hist);
+      rc = sort_pairs(c, n, n_passes, dflt ? 0 : 16, dflt ? 1 : 0, fuse_hist);
+      if (!rc && dflt && n_passes > 1) {   // more than one pass: where each bucket lies is found by a pass of its own
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(grid), dim3(256), 0, c->stream, (const u64 *) c->d_kA, (const u64 *) c->d_kB, c->d_M, c->d_bLo, c->d_bHi,
+                           c->d_bList, c->nbcap, c->G.err);
+        HIPCHK(hipGetLastError());
+      }
     }
     if (rc) return rc;
     PhaseTimer t(c, MM_PHASE_MERGE);
     if (dflt) {
-      // exactly one of the two does the work (device-side decision, batch_is_leaf): k_leaf behind the partition pass of the leaf
-      // layout, k_chunk_default behind the full sort or - name-grouped input - the plain compaction
-      hipLaunchKernelGGL(k_leaf, dim3(RS_BINS), dim3(LEAF_THREADS), 0, c->stream, (const u64 *) c->d_kB, c->d_M, c->d_rowTot, d_aln, d_big, (u32) n_big, hm,
-                         c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, force_leaf ? 1 : 0);
+      // exactly one of the two does the work (device-side decision, batch_is_leaf): k_leaf behind the partition passes,
+      // k_chunk_default behind the plain compaction of name-grouped input
+      hipLaunchKernelGGL(k_leaf, dim3(RS_BINS), dim3(LEAF_THREADS), 0, c->stream, (const u64 *) c->d_kA, (const u64 *) c->d_kB, c->d_M, c->d_rowTot, c->d_bLo, c->d_bHi,
+                         c->d_bList, d_aln, d_big, (u32) n_big, hm, c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, force_leaf ? 1 : 0);
       if (!force_leaf)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_aln, d_big, (u32) n_big, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
