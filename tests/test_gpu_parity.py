@@ -443,3 +443,42 @@ def test_every_grouping_layout(gpu_lib, oracle, stride, shuffle):
         assert (r["hit"] == ref.hit_mask).all()
         assert r["stats"] == ref.stats, (stride, shuffle, batches)
         assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (stride, shuffle, batches)
+
+
+@pytest.mark.parametrize("order", ["interleaved", "grouped", "far"])
+def test_leaf_merge_at_scale(gpu_lib, oracle, order):
+    """The multi-hit merge on ~1.1 M records of 200 k read names, a quarter of them malformed (over-complete, under-complete, mixed NH)
+    - dozens of 4096-name buckets per batch, every one holding order-dependent names, tens of replay chunks per bucket - in three
+    arrangements: hits of a read a few thousand records apart (one partition pass), adjacent (the runs of equal names that k_leaf
+    reduces inside a wave), and read-name ids spread out so that two partition passes + k_bucket_bounds are needed.  Table and
+    counters equal the oracle's, in one batch and in five."""
+    mm = gpu_lib
+    rng = np.random.default_rng(77)
+    desc = sr.random_config(rng, n_lines=5, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=3000, maxpos=150000)
+    names = 200_000
+    k = rng.integers(2, 9, names)                                    # NH of the name
+    recs = k.copy()
+    r = rng.random(names)
+    over = r < 0.10; recs[over] += rng.integers(1, 2 * k[over] + 1)  # over-complete (e.g. both mates under one name)
+    under = (r >= 0.10) & (r < 0.18); recs[under] = np.maximum(1, k[under] - rng.integers(1, k[under]))
+    qid = np.repeat(np.arange(names, dtype=np.int64), recs)
+    nh = np.repeat(k, recs).astype(np.uint32)
+    mixed = np.repeat((r >= 0.18) & (r < 0.26), recs)
+    nh[mixed] = rng.integers(1, 9, int(mixed.sum()))                 # mixed NH inside one name (NH 1 records bypass the group)
+    n = len(qid)
+    pick = rng.integers(0, len(ix["start"]), n)
+    start = np.maximum(1, ix["start"][pick] + rng.integers(-80, 80, n))
+    reads = dict(tid=ix["chr"][pick].astype(np.int32), start=start.astype(np.int64), end=(start + rng.integers(20, 120, n)).astype(np.int64),
+                 strand=rng.integers(0, 2, n).astype(np.uint8), nh=nh, qid=qid)
+    if order != "grouped":
+        perm = np.argsort(np.arange(n) + rng.random(n) * 5000.0, kind="stable")      # hits of a read up to ~5000 records apart
+        reads = {key: v[perm] for key, v in reads.items()}
+    if order == "far":
+        reads = dict(reads, qid=reads["qid"] * 300)                                   # 26 key bits: two partition passes
+    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy="default")
+    cfg = to_cfg(mm, desc)
+    for batches in (1, 5):
+        got = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="F", strategy="default", batches=batches, keep=False)
+        assert got["stats"] == ref.stats, (order, batches)
+        assert got["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order, batches)
