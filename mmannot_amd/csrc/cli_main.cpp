@@ -14,6 +14,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -106,9 +107,12 @@ struct Staging {
   mm_aln *buf[3] = {nullptr, nullptr, nullptr};
   std::vector<mm_nh_big> big;
   std::vector<uint64_t> hm;
-  bool ok() const { return buf[0] && buf[1] && buf[2]; }
-  Staging() { for (auto &b : buf) b = (mm_aln *) mm_host_alloc(batch() * sizeof(mm_aln)); big.resize(1 << 16); }
-  ~Staging() { for (auto &b : buf) mm_host_free(b); }
+  int n_buf;
+  bool ok() const { for (int k = 0; k < n_buf; ++k) if (!buf[k]) return false; return true; }
+  explicit Staging(int n = 3) : n_buf(n) { for (int k = 0; k < n_buf; ++k) buf[k] = (mm_aln *) mm_host_alloc(batch() * sizeof(mm_aln)); big.resize(1 << 16); }
+  Staging(const Staging &) = delete;
+  Staging &operator=(const Staging &) = delete;
+  ~Staging() { for (auto &b : buf) mm_host_free(b); }   // (mm_host_free(NULL) is a no-op)
 };
 
 // -y random across input files (sequential runs): the reference's Counter keeps `seen`, `chosenId` and `numberSeen` - all keyed
@@ -509,9 +513,11 @@ int main(int argc, char **argv) {
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, false);
     if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
-    std::vector<Staging> stg(N);                    // per device: three pinned buffers of a full batch
-    Staging decode;                                 // where the decoder writes before the batch is dealt out
-    for (auto &g : stg) if (!g.ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    std::vector<std::unique_ptr<Staging>> stg_own;  // per device: three pinned buffers of a full batch
+    for (size_t d = 0; d < N; ++d) stg_own.emplace_back(new Staging(3));
+    auto stg = [&](size_t d) -> Staging & { return *stg_own[d]; };
+    Staging decode(1);                              // where the decoder writes before the batch is dealt out
+    for (size_t d = 0; d < N; ++d) if (!stg(d).ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     if (!decode.ok()) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     std::vector<size_t> submitted(N, 0), part_n(N), part_nbig(N);
     std::vector<uint32_t> part_max(N);
@@ -524,8 +530,8 @@ int main(int argc, char **argv) {
       size_t n = 0, n_big = 0;
       uint32_t max_nh = 0;
       const size_t dr = batch_no % N;              // -y ratio: the device this whole batch goes to
-      mm_aln *aln = ratio ? stg[dr].buf[submitted[dr] % 3] : decode.buf[0];
-      std::vector<mm_nh_big> &big = ratio ? stg[dr].big : decode.big;
+      mm_aln *aln = ratio ? stg(dr).buf[submitted[dr] % 3] : decode.buf[0];
+      std::vector<mm_nh_big> &big = ratio ? stg(dr).big : decode.big;
       const auto t0 = now();
       rc = mm_reader_next(rd, aln, BATCH, &n, big.data(), big.size(), &n_big, &max_nh);
       err << mm_reader_take_log(rd);
@@ -537,8 +543,8 @@ int main(int argc, char **argv) {
         if (mm_annotate_batch(ctxs[dr], aln, n, big.data(), n_big, 0, 0, 0) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
         ++submitted[dr];
       } else {
-        for (size_t d = 0; d < N; ++d) { part_out[d] = stg[d].buf[submitted[d] % 3]; part_big[d] = stg[d].big.data(); }
-        if (mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg[0].big.size(), part_nbig.data(),
+        for (size_t d = 0; d < N; ++d) { part_out[d] = stg(d).buf[submitted[d] % 3]; part_big[d] = stg(d).big.data(); }
+        if (mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg(0).big.size(), part_nbig.data(),
                          part_max.data(), part_qlo.data()) != MM_OK) { err << "mmannot-amd: cannot deal the batch out to the devices" << std::endl; return EXIT_FAILURE; }
         const uint64_t qb = (mm_reader_qid_bound(rd) + N - 1) / N;
         for (size_t d = 0; d < N; ++d) {

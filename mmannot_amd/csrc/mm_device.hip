@@ -3,7 +3,7 @@
 // Reference behaviour (mzytnicki/mmannot v1.1, mmannot.cpp):
 //   IntervalList::scan            :1291-1332   -> k_probe (candidate enumeration + strand + -l filter)
 //   EvaluationStructure::getFirst :1029-1076   -> priority selection inside k_probe
-//   Counter::addCount             :1665-1739   -> k_probe (per-hit branch), k_chunk_default (multi-hit
+//   Counter::addCount             :1665-1739   -> k_probe (per-hit branch), k_leaf / k_chunk_default (multi-hit
 //                                                 countdown / union), k_ratio_tiles + k_ratio_rows (-y ratio)
 //   Counter::read flush           :1783-1792   -> k_flush_pending
 //   Counter::getCounts / dump     :1803-1818   -> mm_get_rows / mm_get_stats
@@ -17,9 +17,11 @@
 //   * compact slots (probe_slots): one 64-B sector per bin with up to 7 packed 8-B records - every read with end >= start;
 //   * full 16-B records + bins + active lists (probe_one): reads without CIGAR operations (they need the "leading
 //     isBefore run" rule, which uses each record's prefix-max of ends) and the -M interval listing.
-// Downstream of the probe: multi-hit records are stably radix-sorted by read-name id and reduced per name (k_rs_*,
-// k_chunk_default); -y ratio sorts by element set and accumulates each row's doubles in file order, exactly but in
-// parallel (k_ratio_tiles, k_ratio_rows).  See DESIGN.md.
+// Downstream of the probe: multi-hit records are brought together by bucket of 4096 read names with stable partition passes
+// (k_rs_*; one pass for a key range of 21 bits) and each bucket is reduced per name in LDS (k_leaf) - no full sort, no
+// per-name gathers; name-grouped input with a wide key range is only compacted and reduced by k_chunk_default.  -y ratio sorts
+// by element set and accumulates each row's doubles in file order, exactly but in parallel (k_ratio_tiles, k_ratio_rows).
+// See DESIGN.md.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
