@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(256) void k_flush_pending(u32 *__restrict__ grpRem,
 #define RATIO_SERIAL_STEP 1024      // a chunk that cannot be reduced is replayed this many terms at a time
 #define RATIO_CHUNK (RATIO_THREADS * RATIO_PER_THREAD)
 #define RATIO_SLOTS_PER_WG 128
+#define RATIO_SHORT_ROW 96          // rows with at most this many terms in a batch are summed by a single lane
 
 __global__ __launch_bounds__(256) void k_seg_bounds(const u32 *__restrict__ skeys, const u32 *__restrict__ info, u32 *__restrict__ segLo,
                                                     u32 *__restrict__ segHi) {
@@ -1586,7 +1587,19 @@ __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restr
   int kLut = 0x7fffffff;
   // this workgroup's slots: one coalesced read of their segment bounds instead of a dependent load per slot
   const u32 slot0 = blockIdx.x * RATIO_SLOTS_PER_WG;
-  if (t < RATIO_SLOTS_PER_WG) { sLo[t] = segLo[slot0 + t]; sHi[t] = segHi[slot0 + t]; }
+  if (t < RATIO_SLOTS_PER_WG) {
+    u32 lo = segLo[slot0 + t], hi = segHi[slot0 + t];
+    // Short rows first, each by ONE lane, all of them at once: most rows of a table are element sets that collect a handful of hits
+    // per batch (ambiguous combinations), and the file-order sum of a few terms is just that - a loop of IEEE adds
+    // (mmannot.cpp:1730).  The workgroup-wide machinery below is for the rows that collect thousands.
+    if (hi > lo && hi - lo <= RATIO_SHORT_ROW && row_in_chunk(G.key[slot0 + t], chunk, nchunks)) {
+      double S = G.sum[slot0 + t];
+      for (u32 j = lo; j < hi; ++j) S = __dadd_rn(S, __ddiv_rn(1.0, (double) svals[j]));
+      G.sum[slot0 + t] = S;
+      hi = lo;                                               // done
+    }
+    sLo[t] = lo; sHi[t] = hi;
+  }
   __syncthreads();
   for (u32 si = 0; si < RATIO_SLOTS_PER_WG; ++si) {
     const u32 slot = slot0 + si;

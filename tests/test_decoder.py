@@ -142,3 +142,53 @@ def test_header_larger_than_a_batch_and_cut_records(oracle, tmp_path):
         b = _decode(pb, an, cap=4099)
         assert len(a[0]) == n and (a[0] == b[0]).all() and (a[1] == b[1]).all()
         assert a[2:] == b[2:]
+
+
+def test_corrupted_records_framed_equals_sequential(oracle, tmp_path, monkeypatch):
+    """Differential fuzz: a few bytes of the record stream are overwritten (random bytes, bit flips, implausible block sizes).  What
+    the reference does with such a file is whatever its sequential parser does; the framed / parallel path must do the same - same
+    tuples, names, messages, or the same error - because it hands every record it cannot vouch for to that parser and falls back
+    to reading sequentially once the framing and the parser disagree."""
+    import struct
+    import mmannot_amd.api as api
+    from mmannot_amd import MMError
+    kat = os.path.join(gu.GOLD, "kat", "X1_xa")
+    an = api.Annotation(os.path.join(kat, "c.cfg"), os.path.join(kat, "a.gtf"))
+    rng = np.random.default_rng(123)
+    n = 20000
+    chroms = [("chr1", 100000), ("chrZ", 50000)]
+    body = oracle.bam_records_fixed(rng.integers(-1, 2, n), rng.integers(0, 90000, n), rng.integers(0, 32, n).astype(np.uint16) & 16,
+                                    rng.integers(0, 5000, n), rng.integers(20, 150, n), rng.integers(0, 9, n).astype(np.uint32))
+    refs = b"".join(struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln) for nm, ln in chroms)
+    hdr = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", len(chroms)) + refs
+
+    def decode(path):
+        try:
+            d = api.ReadsDecoder(path, an)
+            a, h = d.read_all(cap=3001)
+            return ("ok", a.tobytes(), h.tobytes(), d.take_log().replace(path, "F"), d.qid_bound())
+        except MMError as e:
+            return ("err", str(e).replace(path, "F"))
+
+    outcomes = set()
+    for trial in range(14):
+        b = bytearray(body)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                b[pos:pos + 4] = struct.pack("<i", int(rng.integers(-5, 400)))
+        path = str(tmp_path / f"fuzz{trial}.bam")
+        oracle.write_bgzf(path, hdr + bytes(b), level=1, block=int(rng.choice([3001, 0xff00, 977])))
+        monkeypatch.delenv("MM_READER_GENERAL", raising=False)
+        fast = decode(path)
+        monkeypatch.setenv("MM_READER_GENERAL", "1")
+        gen = decode(path)
+        monkeypatch.delenv("MM_READER_GENERAL", raising=False)
+        assert fast == gen, trial
+        outcomes.add(fast[0])
+    assert "ok" in outcomes
