@@ -71,6 +71,10 @@ def main():
                     "an aligner's own output order; default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--legs", default="both", choices=("both", "host", "resident"), help="profiling aid: run only one leg (the JSON line of record needs both)")
+    ap.add_argument("--tuple-bytes", type=int, default=16, choices=(16, 12),
+                    help="bytes per tuple on the link in the from-host leg that gives `value`: 16 = mm_aln (SURVEY.md 8d, the metric of record); "
+                         "12 = the packed link format (mm_pack12 where the tuples are produced, expanded on the device).  With 16 the packed "
+                         "format is still measured, in a leg of its own, and reported beside `value` as `from_host_packed12`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
     args = ap.parse_args()
@@ -157,17 +161,29 @@ def main():
     if nh_max > 1 and strategy == "default":
         ctr.reserve(qb)         # the per-read-name state is sized once, before any timing (a decoder that knows the number of reads)
 
-    def run_leg(from_host: bool):
+    def run_leg(from_host: bool, pk12: bool = False):
         """W warm-up steps, then K timed steps + end-of-file flush + cross-rank merge, bracketed by barrier + synchronize.
         Returns (elapsed seconds = max over ranks, phases of the timed region, masks, sums, stats)."""
         host = None
         if from_host:   # pinned host copies of the same batches: the library's copy stream moves them (hipMemcpyAsync)
             host = [a.cpu().pin_memory() for a in alns]
+            if pk12:    # ... packed to 12 bytes per tuple where they are produced (here: now, outside every timed region)
+                packed, bases = [], []
+                for h in host:
+                    h16 = h.numpy().view(mm.ALN_DTYPE).reshape(-1)
+                    base = int(h16["qid"].min())
+                    out = torch.empty(B * 12, dtype=torch.uint8).pin_memory()
+                    nbig = C.c_size_t(0)
+                    _lib.check(_lib.lib().mm_pack12(h16.ctypes.data, B, None, 0, base, C.c_void_p(out.data_ptr()), None, 0, C.byref(nbig)))
+                    packed.append(out); bases.append(base)
+                host = packed
         ctr.clear()
         ctr.set_profiling(0)
 
         def step(s):
-            if host is not None:
+            if host is not None and pk12:
+                ctr.add_batch_host12(host[s].data_ptr(), B, bases[s], qbound(s), single_hit=single, qid_lo=qlo(s))
+            elif host is not None:
                 ctr.add_batch_host(host[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
             else:
                 ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
@@ -210,8 +226,13 @@ def main():
         del host
         return float(el.item()), phases, masks, sums, stats
 
-    res_host = run_leg(True) if args.legs in ("both", "host") else None
+    res_host = run_leg(True, args.tuple_bytes == 12) if args.legs in ("both", "host") else None
+    res_pk = run_leg(True, True) if (args.legs == "both" and args.tuple_bytes == 16) else None      # the same job with 12 bytes per tuple on the link
     res_dev = run_leg(False) if args.legs in ("both", "resident") else None
+    if res_host is not None and res_pk is not None:
+        oh, op = np.argsort(res_host[2]), np.argsort(res_pk[2])
+        assert res_host[4] == res_pk[4] and np.array_equal(res_host[2][oh], res_pk[2][op])
+        assert np.array_equal(np.ascontiguousarray(res_host[3][oh]).view(np.uint64), np.ascontiguousarray(res_pk[3][op]).view(np.uint64))
     if res_host is not None and res_dev is not None:   # the two legs are the same job
         oh, od = np.argsort(res_host[2]), np.argsort(res_dev[2])
         assert res_host[4] == res_dev[4] and np.array_equal(res_host[2][oh], res_dev[2][od])
@@ -244,19 +265,30 @@ def main():
             "vs_baseline": None, "dtype": "int32/u64 (f64 only under -y ratio)", "data": "synthetic",
             "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "order_elements": len(an.config),
                        "index_bytes": info, "sharding": "by read name, table merged by all_gather+all_reduce",
-                       "input": "16-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region" if res_host is not None
+                       "input": f"{args.tuple_bytes}-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region" if res_host is not None
                                 else "tuples resident in HBM (--legs resident: NOT the metric of record)"},
             "stats": stats, "table_rows": int(len(masks)),
         }
         if res_host is not None:
             h_ms, h_n = res_host[1]["h2d"]
             avg_copy_s = h_ms / max(1, h_n) / 1e3
-            link = B_ALG_H2D * B / avg_copy_s / 1e9 if avg_copy_s > 0 else 0.0
+            link_b = float(args.tuple_bytes)
+            link = link_b * B / avg_copy_s / 1e9 if avg_copy_s > 0 else 0.0
             out["h2d"] = {"bound": "pcie", "achieved": link, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": link / PCIE_PEAK_GBS,
-                          "alg_bytes_per_alignment": B_ALG_H2D, "avg_copy_ms": avg_copy_s * 1e3,
-                          "end_to_end": out["value"] / world * B_ALG_H2D / 1e9,
-                          "note": "achieved = 16 B x batch / average hipMemcpyAsync duration (HIP events on the copy stream, timed region); "
-                                  "end_to_end = per-GPU value x 16 B: what the whole pipeline sustains on the link"}
+                          "alg_bytes_per_alignment": B_ALG_H2D, "link_bytes_per_alignment": link_b, "avg_copy_ms": avg_copy_s * 1e3,
+                          "end_to_end": out["value"] / world * link_b / 1e9,
+                          "note": "achieved = bytes per tuple on the link x batch / average hipMemcpyAsync duration (HIP events on the copy stream, "
+                                  "timed region); end_to_end = per-GPU value x those bytes: what the whole pipeline sustains on the link"}
+            if args.tuple_bytes != 16:
+                out["metric"] = "annotated alignments/sec, tuples packed to 12 B on the link (informational; the metric of record uses 16-B tuples)"
+        if res_pk is not None:
+            p_el = res_pk[0]
+            p_ms, p_n = res_pk[1]["h2d"]
+            p_copy_s = p_ms / max(1, p_n) / 1e3
+            out["from_host_packed12"] = {"value": job / p_el, "unit": "alignments/s", "ms_per_step": p_el / args.steps * 1e3, "link_bytes_per_alignment": 12.0,
+                                         "link_achieved_GBs": 12.0 * B / p_copy_s / 1e9 if p_copy_s > 0 else 0.0,
+                                         "note": "same job, same table; the tuples cross the link in the 12-byte format (mm_pack12 where they are "
+                                                 "produced, k_expand12 on the device) - not the metric of record, which is quoted on 16-byte tuples"}
         if res_dev is not None:
             k_el, k_ph = res_dev[0], res_dev[1]
             dom = max(("probe", "sort", "merge", "compact"), key=lambda p: phases_all[p][0])

@@ -153,6 +153,20 @@ int mm_reserve_qids(mm_ctx *ctx, uint64_t qid_bound);
 enum { MM_BATCH_ON_DEVICE = 1, MM_BATCH_SINGLE_HIT = 2 };
 int mm_annotate_batch(mm_ctx *ctx, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo, uint64_t qid_bound,
                       uint32_t flags);
+/* Optional 12-byte link format.  From pinned host memory the path runs at the speed of the link (16 B per alignment at ~56 GB/s of
+ * PCIe Gen5 x16 = 3.5 G alignments/s; the kernels take 27 G/s), so what crosses the link is worth packing: w[0] = start:31 | strand:1;
+ * w[1] = length:14 (end - start + 1; 0 for a record without CIGAR operations) | NH:8 (255 = see the side list) | (chromosome+1) bits 9..0;
+ * w[2] = (qid - qid_base):24 | (chromosome+1) bits 17..10.  mm_pack12 (host, where the tuples are produced) refuses a batch with a
+ * tuple that does not fit (MM_ERR_RANGE: it then travels as mm_aln); out_big receives the NH values >= 255 (capacity big_cap).
+ * mm_annotate_batch12 copies 12 bytes per tuple and expands them on the device (k_expand12) into the 16-byte tuples every kernel reads:
+ * same results by construction.  Everything else as mm_annotate_batch. */
+typedef struct mm_aln12 {
+  uint32_t w[3];
+} mm_aln12;
+int mm_pack12(const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_base, mm_aln12 *out, mm_nh_big *out_big, size_t big_cap,
+              size_t *out_n_big);
+int mm_annotate_batch12(mm_ctx *ctx, const mm_aln12 *aln, size_t n, uint64_t qid_base, const mm_nh_big *big, size_t n_big, uint64_t qid_lo,
+                        uint64_t qid_bound, uint32_t flags);
 /* pinned (page-locked) host memory for tuple batches: hipHostMalloc / hipHostFree */
 void *mm_host_alloc(size_t bytes);
 void mm_host_free(void *p);

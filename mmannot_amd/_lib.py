@@ -63,6 +63,8 @@ SYMBOLS = {
     "mm_reset": (C.c_int, [C.c_void_p]),
     "mm_reserve_qids": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mm_annotate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "mm_pack12": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mm_annotate_batch12": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32]),
     "mm_host_alloc": (C.c_void_p, [C.c_size_t]),
     "mm_host_free": (None, [C.c_void_p]),
     "mm_sync": (C.c_int, [C.c_void_p]),

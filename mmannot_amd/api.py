@@ -57,6 +57,24 @@ def nh_side_list(nh) -> np.ndarray:
     return big
 
 
+ALN12_DTYPE = np.dtype([("w", "<u4", (3,))])                                                  # mm_aln12, 12 bytes
+
+
+def pack12(aln: np.ndarray, big: Optional[np.ndarray] = None, qid_base: int = 0):
+    """16-byte tuples (+ their NH side list) -> the 12-byte link format and its side list (NH >= 255); raises MMError(MM_ERR_RANGE)
+    when a tuple does not fit (the batch then travels as 16-byte tuples)."""
+    aln = np.ascontiguousarray(aln)
+    assert aln.dtype == ALN_DTYPE
+    nb = 0 if big is None else len(big)
+    out = np.empty(len(aln), dtype=ALN12_DTYPE)
+    ob = np.empty(max(64, len(aln)), dtype=NH_BIG_DTYPE)
+    n_out = C.c_size_t(0)
+    rc = lib().mm_pack12(aln.ctypes.data, len(aln), big.ctypes.data if nb else None, nb, int(qid_base), out.ctypes.data, ob.ctypes.data, len(ob), C.byref(n_out))
+    if rc != 0:
+        raise _lib.MMError(rc, "mm_pack12: a tuple does not fit the 12-byte format" if rc == 3 else "mm_pack12: bad argument")
+    return out, ob[:n_out.value].copy()
+
+
 def aln_tid(aln) -> np.ndarray:
     return (aln["tsn"] >> np.uint32(NH_BITS + 1)).astype(np.int64) - 1
 
@@ -226,6 +244,23 @@ class Counter:
         flags = _lib.MM_BATCH_ON_DEVICE | (_lib.MM_BATCH_SINGLE_HIT if single_hit else 0)
         nb = 0 if big is None else len(big)
         check(lib().mm_annotate_batch(self._h, C.c_void_p(aln_ptr), int(n), big.ctypes.data if nb else None, nb, int(qid_lo), int(qid_bound), flags))
+
+    def add_batch12(self, pk: np.ndarray, big: Optional[np.ndarray], qid_base: int, qid_bound: int, single_hit: bool = False, qid_lo: int = 0,
+                    on_device_ptr: Optional[int] = None):
+        """12-byte tuples (pack12): host array, or - on_device_ptr - already resident in HBM."""
+        nb = 0 if big is None else len(big)
+        flags = (_lib.MM_BATCH_SINGLE_HIT if single_hit else 0) | (_lib.MM_BATCH_ON_DEVICE if on_device_ptr else 0)
+        if on_device_ptr is None:
+            pk = np.ascontiguousarray(pk)
+            assert pk.dtype == ALN12_DTYPE
+            self._keep.append(pk)
+        ptr = on_device_ptr if on_device_ptr else pk.ctypes.data
+        check(lib().mm_annotate_batch12(self._h, C.c_void_p(ptr), len(pk), int(qid_base), big.ctypes.data if nb else None, nb, int(qid_lo), int(qid_bound), flags))
+
+    def add_batch_host12(self, pk_ptr: int, n: int, qid_base: int, qid_bound: int, single_hit: bool = False, qid_lo: int = 0):
+        """12-byte tuples in (pinned) host memory the caller keeps alive."""
+        check(lib().mm_annotate_batch12(self._h, C.c_void_p(pk_ptr), int(n), int(qid_base), None, 0, int(qid_lo), int(qid_bound),
+                                        _lib.MM_BATCH_SINGLE_HIT if single_hit else 0))
 
     def add_batch_host(self, aln_ptr: int, n: int, qid_bound: int, single_hit: bool = False, qid_lo: int = 0):
         """Packed tuples in (pinned) host memory the caller keeps alive (see the lifetime rule of mm_annotate_batch)."""

@@ -606,6 +606,18 @@ __device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, const uint2 *ch
                                     : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
 }
 
+// 12-byte link format of a tuple (mm_aln12, include/mmannot_amd.h) -> the 16-byte tuple every kernel reads.  Lossless; what does
+// not fit the narrower fields never gets packed (mm_pack12 refuses the batch).
+__global__ __launch_bounds__(256) void k_expand12(const u32 *__restrict__ pk, int4 *__restrict__ out, size_t n, u32 qid_base) {
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+    const u32 w0 = __builtin_nontemporal_load(pk + 3 * i), w1 = __builtin_nontemporal_load(pk + 3 * i + 1), w2 = __builtin_nontemporal_load(pk + 3 * i + 2);
+    const int start = (int) (w0 & 0x7FFFFFFFu);
+    const u32 len = w1 & 0x3FFFu, nh8 = (w1 >> 14) & 0xFFu, tid1 = (w1 >> 22) | ((w2 >> 24) << 10);
+    const u32 nh = nh8 == 255u ? (u32) MM_ALN_NH_ESCAPE : nh8;
+    out[i] = make_int4(start, start + (int) len - 1, (int) ((w0 >> 31) | (nh << 1) | (tid1 << (MM_ALN_NH_BITS + 1))), (int) (qid_base + (w2 & 0xFFFFFFu)));
+  }
+}
+
 // ----------------------------------------------------------------------------- k_probe
 // One lane per alignment, grid-stride over the batch.  Per alignment: scan+getFirst, the
 // three per-hit counters of addCount (mmannot.cpp:1666-1668), then either
@@ -1870,6 +1882,8 @@ struct mm_ctx {
   int4 *d_aln = nullptr;   // = d_alnBuf[cur]
   // host-tuple path: two staging sets filled by a dedicated copy stream, so the copy of batch k+1 overlaps the kernels of batch k
   int4 *d_alnBuf[2] = {nullptr, nullptr};
+  u32 *d_pkBuf[2] = {nullptr, nullptr};   // 12-byte tuples as they cross the link (mm_annotate_batch12), expanded into d_alnBuf
+  size_t pk_cap = 0;
   // NH values too large for the tuple's NH field: the caller's (index, NH) list, staged through pinned memory (two sets)
   uint2 *d_big[2] = {nullptr, nullptr}, *h_big[2] = {nullptr, nullptr};
   size_t big_cap[2] = {0, 0};
@@ -2155,6 +2169,8 @@ extern "C" int mm_index_info(const mm_index *ix, uint64_t info[8]) {
 
 static void ctx_free_batch(mm_ctx *c) {
   for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_alnBuf[b]); c->d_alnBuf[b] = nullptr; c->consumed_valid[b] = false; c->copied_valid[b] = false; }
+  for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_pkBuf[b]); c->d_pkBuf[b] = nullptr; }
+  c->pk_cap = 0;
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_kB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
@@ -2383,8 +2399,9 @@ static int stage_big(mm_ctx *c, const mm_nh_big *big, size_t n_big, size_t n, co
   return MM_OK;
 }
 
-extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo, uint64_t qid_bound,
-                                 uint32_t flags) {
+// one batch; fmt12: `aln` holds 12-byte tuples (mm_aln12) relative to qid_base, expanded on the device behind the copy
+static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_base, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo,
+                         uint64_t qid_bound, uint32_t flags) {
   if (!c) return fail(MM_ERR_ARG, "mm_annotate_batch: null context");
   if (c->finalized) return fail(MM_ERR_STATE, "mm_annotate_batch: context already finalized (call mm_reset)");
   if (n == 0) return MM_OK;
@@ -2395,8 +2412,14 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   if (single && n_big) return fail(MM_ERR_ARG, "mm_annotate_batch: MM_BATCH_SINGLE_HIT with an NH side list");
   if (qid_lo > qid_bound || qid_lo > 0xFFFFFFF0ull) qid_lo = 0;   // (a hint only)
   HIPCHK(hipSetDevice(c->ix->device));
-  int rc = ensure_batch(c, n, !on_device);
+  int rc = ensure_batch(c, n, !on_device || fmt12);
   if (rc) return rc;
+  if (fmt12 && c->pk_cap < c->cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
+    for (int b = 0; b < 2; ++b) { (void) hipFree(c->d_pkBuf[b]); c->d_pkBuf[b] = nullptr; HIPCHK(hipMalloc((void **) &c->d_pkBuf[b], c->cap * 12)); }
+    c->pk_cap = c->cap;
+  }
   const bool dflt = c->opt.strategy == MM_STRAT_DEFAULT, ratio = c->opt.strategy == MM_STRAT_RATIO;
   if (dflt && !single) { rc = ensure_qids(c, qid_bound ? qid_bound : 1); if (rc) return rc; }
   const uint2 *d_big = nullptr;
@@ -2404,7 +2427,14 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   if (rc) return rc;
   const int4 *d_aln = (const int4 *) aln;
   int staged = -1;
-  if (!on_device) {
+  const u32 egrid = (u32) std::min<size_t>((n + 255) / 256, 256 * 16);
+  if (on_device && fmt12) {   // packed tuples already in HBM: expand into a staging set (no copy, but the set is in use until the batch is done)
+    const int b = c->cur; c->cur ^= 1; staged = b;
+    if (c->consumed_valid[b]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_consumed[b], 0));
+    hipLaunchKernelGGL(k_expand12, dim3(egrid), dim3(256), 0, c->stream, (const u32 *) aln, c->d_alnBuf[b], n, (u32) qid_base);
+    c->d_aln = c->d_alnBuf[b];
+    d_aln = c->d_aln;
+  } else if (!on_device) {
     // copy stream: wait until the kernels that last read this staging set are done, copy, signal; the compute stream
     // waits for the signal.  With two sets the copy of this batch overlaps the kernels of the previous one.
     const int b = c->cur; c->cur ^= 1; staged = b;
@@ -2416,10 +2446,12 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
       PhaseTimer t(c, MM_PHASE_H2D);
       t.stream_override = c->copy_stream;
       t.restart();
-      HIPCHK(hipMemcpyAsync(c->d_alnBuf[b], aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->copy_stream));
+      if (fmt12) HIPCHK(hipMemcpyAsync(c->d_pkBuf[b], aln, n * 12, hipMemcpyHostToDevice, c->copy_stream));   // 12 bytes per alignment cross the link
+      else HIPCHK(hipMemcpyAsync(c->d_alnBuf[b], aln, n * sizeof(mm_aln), hipMemcpyHostToDevice, c->copy_stream));
     }
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy_stream)); c->copied_valid[b] = true;
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+    if (fmt12) hipLaunchKernelGGL(k_expand12, dim3(egrid), dim3(256), 0, c->stream, c->d_pkBuf[b], c->d_alnBuf[b], n, (u32) qid_base);
     c->d_aln = c->d_alnBuf[b];
     d_aln = c->d_aln;
   }
@@ -2506,6 +2538,17 @@ extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const m
   }
   if (staged >= 0) { HIPCHK(hipEventRecord(c->ev_consumed[staged], c->stream)); c->consumed_valid[staged] = true; }
   return MM_OK;
+}
+
+extern "C" int mm_annotate_batch(mm_ctx *c, const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, uint64_t qid_lo, uint64_t qid_bound,
+                                 uint32_t flags) {
+  return annotate_impl(c, aln, false, 0, n, big, n_big, qid_lo, qid_bound, flags);
+}
+
+extern "C" int mm_annotate_batch12(mm_ctx *c, const mm_aln12 *aln, size_t n, uint64_t qid_base, const mm_nh_big *big, size_t n_big, uint64_t qid_lo,
+                                   uint64_t qid_bound, uint32_t flags) {
+  if (qid_base > 0xFFFFFFF0ull) return fail(MM_ERR_RANGE, "mm_annotate_batch12: qid_base exceeds 2^32");
+  return annotate_impl(c, aln, true, qid_base, n, big, n_big, qid_lo, qid_bound, flags);
 }
 
 static int check_table(mm_ctx *c) {

@@ -482,3 +482,50 @@ def test_leaf_merge_at_scale(gpu_lib, oracle, order):
         got = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="F", strategy="default", batches=batches, keep=False)
         assert got["stats"] == ref.stats, (order, batches)
         assert got["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order, batches)
+
+
+@pytest.mark.parametrize("strategy", ["default", "ratio", "unique"])
+def test_twelve_byte_link_format(gpu_lib, oracle, strategy):
+    """mm_annotate_batch12: 12 bytes per tuple cross the link and k_expand12 rebuilds the 16-byte tuples on the device - same per-hit
+    sets, counters and table as the oracle (zero-length reads, unknown chromosomes, NH 0..8 and a few NH far beyond the 8-bit
+    field, malformed groups), from host memory and from tuples already resident in HBM, in one batch and in four."""
+    import torch
+    mm = gpu_lib
+    rng = np.random.default_rng(1212)
+    desc = sr.random_config(rng, n_lines=6, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=2500, maxpos=120000)
+    reads = sr.random_reads(rng, ix, n=30000, nchr=3, maxpos=120000, nh_max=8)
+    long_ones = (reads["end"] - reads["start"] + 1) > 16383                      # (the generator makes a few 40 kb reads: beyond the 14-bit length)
+    reads = {k: v[~long_ones] for k, v in reads.items()}
+    nh = reads["nh"].copy()
+    for pos, val in ((100, 255), (5000, 300), (9000, 70000), (20000, 254)):
+        nh[reads["qid"] == int(reads["qid"][pos])] = val
+    reads = dict(reads, nh=nh, qid=reads["qid"] + 1_000_000)
+    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy=strategy, want_hit_mask=True)
+    cfg = to_cfg(mm, desc)
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], ix["n_chromosomes"])
+    aln = mm.pack_alignments(reads["tid"], reads["start"], reads["end"], reads["strand"], reads["qid"], reads["nh"])
+    n = len(aln)
+    qb = int(reads["qid"].max()) + 1
+    for resident in (False, True):
+        for batches in (1, 4):
+            ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy, keep_hit_masks=True)
+            hm = []
+            cuts = np.linspace(0, n, batches + 1).astype(int)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                pk, big12 = mm.pack12(aln[a:b], mm.nh_side_list(reads["nh"][a:b]), qid_base=1_000_000)
+                if resident:
+                    dev = torch.from_numpy(pk.view(np.uint8).reshape(-1).copy()).cuda()
+                    ctr.add_batch12(pk, big12, 1_000_000, qb, on_device_ptr=dev.data_ptr())
+                else:
+                    ctr.add_batch12(pk, big12, 1_000_000, qb, qid_lo=1_000_000)
+                ctr.sync()
+                hm.append(ctr.hit_masks(b - a))
+            ctr.flush()
+            masks, sums = ctr.getCounts()
+            table = mm.TableCount(cfg, 1); table.add_rows(masks, sums)
+            assert (np.concatenate(hm) == ref.hit_mask).all(), (resident, batches)
+            assert ctr.stats() == ref.stats, (resident, batches)
+            assert table.dump(["t"]) == oracle.format_table(desc, ref.row_mask, ref.row_count, "t"), (resident, batches)
+            ctr.close()
+    index.close()

@@ -75,3 +75,47 @@ def test_row_chunk_matches_the_library():
     m = np.random.default_rng(1).integers(1, 1 << 63, 2000, dtype=np.uint64)
     for c in (1, 2, 5, 8, 13):
         assert api.row_chunk(m, c).tolist() == [lib().mm_row_chunk(int(x), c) for x in m]
+
+
+def _unpack12(api, pk, qid_base):
+    """numpy twin of k_expand12 (mm_device.hip)"""
+    w = pk["w"].astype(np.uint64)
+    start = (w[:, 0] & 0x7FFFFFFF).astype(np.int64)
+    ln = (w[:, 1] & 0x3FFF).astype(np.int64)
+    nh8 = (w[:, 1] >> 14) & 0xFF
+    tid1 = (w[:, 1] >> 22) | ((w[:, 2] >> 24) << 10)
+    nh = np.where(nh8 == 255, api.NH_ESCAPE, nh8)
+    out = np.empty(len(pk), dtype=api.ALN_DTYPE)
+    out["start"] = start; out["end"] = start + ln - 1
+    out["tsn"] = ((w[:, 0] >> 31) | (nh << 1) | (tid1 << (api.NH_BITS + 1))).astype(np.uint32)
+    out["qid"] = (qid_base + (w[:, 2] & 0xFFFFFF)).astype(np.uint32)
+    return out
+
+
+def test_pack12_round_trip_and_refusals():
+    """The optional 12-byte link format: packing is lossless (expanded tuples + side list give back start, end - also start-1, a record
+    without CIGAR operations -, chromosome, strand, NH, qid) and a batch with a tuple that does not fit is refused as a whole."""
+    import mmannot_amd.api as api
+    from mmannot_amd import MMError
+    rng = np.random.default_rng(12)
+    n = 50000
+    start = rng.integers(1, 1 << 30, n)
+    ln = rng.integers(0, 16384, n); ln[:50] = 0; ln[50:100] = 16383
+    nh = rng.integers(0, 300, n).astype(np.uint64); nh[rng.integers(0, n, 30)] = rng.integers(2047, 1 << 32, 30)
+    tid = rng.integers(-1, (1 << 18) - 2, n)
+    qid = 5_000_000 + rng.integers(0, 1 << 24, n)
+    aln = api.pack_alignments(tid, start, start + ln - 1, rng.integers(0, 2, n), qid, nh)
+    big = api.nh_side_list(nh)
+    pk, big12 = api.pack12(aln, big, qid_base=5_000_000)
+    assert pk.dtype.itemsize == 12 and len(big12) == int((nh >= 255).sum())
+    back = _unpack12(api, pk, 5_000_000)
+    assert (back["start"] == aln["start"]).all() and (back["end"] == aln["end"]).all() and (back["qid"] == aln["qid"]).all()
+    assert (api.aln_tid(back) == api.aln_tid(aln)).all() and (api.aln_strand(back) == api.aln_strand(aln)).all()
+    assert (api.aln_nh(back, big12) == api.aln_nh(aln, big)).all()
+    for field, value in (("end", int(aln["start"][7]) + 16384), ("qid", 5_000_000 + (1 << 24)), ("qid", 4_999_999)):
+        bad = aln.copy(); bad[field][7] = value
+        with pytest.raises(MMError):
+            api.pack12(bad, big, qid_base=5_000_000)
+    bad = api.pack_alignments([(1 << 18) - 1], [10], [20], [1], [5_000_000], [1])      # chromosome index beyond 18 bits
+    with pytest.raises(MMError):
+        api.pack12(bad, None, qid_base=5_000_000)
