@@ -32,7 +32,10 @@ def test_single_rank_contract(gpu_lib):
     # `value` is the rate from pinned host tuples (copies inside the timed region); the HBM-resident rate is reported beside it
     h, k = d["h2d"], d["kernel_only"]
     assert h["bound"] == "pcie" and h["unit"] == "GB/s" and h["alg_bytes_per_alignment"] == 16.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
-    assert k["value"] > 0 and "pinned host" in d["config"]["input"]
+    assert k["value"] > 0 and "pinned host" in d["config"]["input"] and "16-byte" in d["config"]["input"]
+    assert 0 < k["step_roofline"]["frac"] < 1
+    p = d["from_host_packed12"]      # the same job with 12 bytes per tuple on the link, reported beside the metric of record
+    assert p["value"] > 0 and p["link_bytes_per_alignment"] == 12.0
 
 
 @pytest.mark.timeout(900)
