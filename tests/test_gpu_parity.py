@@ -423,13 +423,14 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
             assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order_kind, batches)
 
 
-@pytest.mark.parametrize("stride,shuffle", [(1, True), (700, True), (700, False), (70000, True)])
+@pytest.mark.parametrize("stride,shuffle", [(1, True), (700, True), (700, False), (70000, True), (400000, True)])
 def test_every_grouping_layout(gpu_lib, oracle, stride, shuffle):
-    """The multi-hit merge picks its path per batch on the device: name-grouped input -> compaction + k_chunk_default; a key range
-    of at most 21 bits -> one partition pass + k_leaf (LDS reduction per bucket of 4096 names, file-order replay of the names
-    whose record order matters); wider ranges -> full LSD sort + k_chunk_default.  Same reads, read-name ids spread out by
-    `stride` to force each layout (3, 4 and - stride 70000 - 31 key bits), malformed groups included: always the oracle's answer,
-    whatever the batch split."""
+    """The multi-hit merge picks its path per batch on the device: a key range of at most 21 bits -> one partition pass by bucket of
+    4096 names + k_leaf (LDS reduction per bucket, file-order replay of the names whose record order matters); wider ranges -> two
+    or three partition passes + k_bucket_bounds + k_leaf; name-grouped input with a wide range -> compaction + k_chunk_default.
+    Same reads, read-name ids spread out by
+    `stride` to force each layout (one, two and - stride 400000, 31 key bits, 50 GB of per-name state - three partition passes;
+    name-grouped with a wide range - the compaction), malformed groups included: always the oracle's answer, whatever the batch split."""
     mm = gpu_lib
     rng = np.random.default_rng(2024)
     desc = sr.random_config(rng, n_lines=6, max_per_line=3)
