@@ -182,6 +182,7 @@ struct ProbeParams {
   const u32 *slotBits;      // one bit per slot: does it hold any record?  NULL when too few slots are empty for the test to pay
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
   u32 sshift;
+  u32 reach;               // a slot also lists the intervals starting in the first `reach` bases of the next bin
   int useSlots;
   u32 nchr;
   u32 shift;
@@ -418,22 +419,46 @@ __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, i
   return ok && ((float) ov >= P.overlapValue);
 }
 
+// rec_pass for a record whose end is already known, as a 0/1 value (no branch)
+template <int OVL>
+__device__ __forceinline__ u32 span_pass(const ProbeParams &P, int is, int ie, u32 ok, int s, int e) {
+  if (OVL == MM_OVL_INCLUSION) return ok & (u32) (is <= s) & (u32) (e <= ie);
+  const int lo = max(s, is), hi = min(e, ie);
+  const u32 ov = (u32) (hi - lo);
+  if (OVL == MM_OVL_PC) {
+    const u32 size = (u32) (e - s + 1);
+    const float lhs = __fmul_rn((float) size, P.overlapValue);
+    return ok & (u32) (lo < hi) & (u32) (lhs <= (float) ov);
+  }
+  return ok & (u32) (lo < hi) & (u32) ((float) ov >= P.overlapValue);
+}
+
+// number of reach records behind a slot's own (second header word: the count itself while the whole list fits the 7 inline records,
+// else the list's offset in flat, >= 8, with the count in the record before it)
+__device__ __forceinline__ u32 slot_reach_count(const ProbeParams &P, u32 w1) {
+  return w1 < 8u ? w1 : P.flat[w1 - 1].x;
+}
+
 // The slot walk, written once as a statement macro and expanded with two visitors (plain straight-line code: callbacks made
 // the compiler keep closures and a copy of the parameter block in scratch).  VISIT(rx, ry) sees, in index order, every
 // record that can concern the read [s,e] (e >= s): the whole slot of the bin of s, then only the "starts here" part of
-// the following bins up to the bin of e.  The slot's first 32 bytes (header + 3 records) are requested first, its
+// the following bins up to the bin of e - or, for a read that ends within `reach` bases of the next bin, the reach records
+// at the end of the first slot instead (the same records in the same order, without a second line).  The slot's first 32 bytes (header + 3 records) are requested first, its
 // second 32 bytes only when the header says they hold records - and nothing at all when the
 // slot is empty, which a bitmap small enough to stay in L2 (1 bit per bin) tells: the kernel's limit is the number of
 // random 64-B sector fetches it can keep in flight, and about half of the bins of a genome hold no record.  The test is
 // a dependent L2 access of its own, so the index only carries the bitmap when at least 42 % of the slots are empty
 // (measured: HS38-shaped 49 % empty -8 % probe time, Flybase6-shaped 57 % -3 %, TAIR10-shaped 35 % +3 %).
 #define MM_SLOT_WALK(VISIT)                                                                      \
-  for (u32 b_ = b0; b_ <= b1; ++b_) {                                                            \
+  for (u32 b_ = b0; b_ <= bl; ++b_) {                                                            \
     if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue; /* empty bin: no line to fetch */ \
     const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;                                        \
     const uint4 q0 = S_[0], q1 = S_[1];                                                          \
-    const u32 nAct_ = q0.x & 0xffffu, n_ = nAct_ + (q0.x >> 16);                                 \
+    const u32 nAct_ = q0.x & 0xffffu;                                                            \
+    u32 n_ = nAct_ + (q0.x >> 16);                                                               \
+    if (reach_) n_ += slot_reach_count(P, q0.y);                                                 \
     const u32 first_ = (b_ == b0) ? 0u : nAct_;                                                  \
+    walked_ += n_ - min(first_, n_);               /* records this bin shows the read (profiling aid) */ \
     if (first_ == 0 && n_ > 0) VISIT(q0.z, q0.w)                                                 \
     if (first_ <= 1 && n_ > 1) VISIT(q1.x, q1.y)                                                 \
     if (first_ <= 2 && n_ > 2) VISIT(q1.z, q1.w)                                                 \
@@ -464,17 +489,72 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
   const uint2 cs = chrSlot[tid1 - 1];
   const u32 nb = cs.y;
   if (nb == 0) return 0;
-  const u32 b0 = min((u32) s >> P.sshift, nb - 1), b1 = min((u32) e >> P.sshift, nb - 1);
+  const u32 eb = (u32) e >> P.sshift;
+  const u32 b0 = min((u32) s >> P.sshift, nb - 1), b1 = min(eb, nb - 1);
+  // a read that ends less than `reach` bases into the next bin finds that bin's candidates at the end of its own slot
+  const bool reach_ = b1 == b0 + 1 && eb == b1 && (u32) e - (b1 << P.sshift) < P.reach;
+  const u32 bl = reach_ ? b0 : b1;
   // pass 1: which elements have a passing interval
+  // The kernel is bound by instruction issue, not by the sector fetches (SQ counters, profiles/r02e_c3_sq_counters.txt),
+  // so the seven records of a slot line are tested without a branch each: a record outside [first, n) or failing the
+  // test ORs in a zero.  Ends of the rare intervals too long for the 22-bit length field are patched in beforehand.
   u64 hit = 0;
+  u32 walked_ = 0;
+#define MM_TEST(RX, RY, IE, VALID)                                                                                   \
+  hit |= (u64) ((u32) (VALID) & span_pass<OVL>(P, (int) (RX), (IE), ((RY) >> (REC_OKBIT + rstrand)) & 1u, s, e)) << REC_TYPE(RY);
 #define MM_VISIT1(RX, RY)                                                                  \
   {                                                                                        \
     u32 o_; int ie_;                                                                       \
     if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) hit |= 1ull << REC_TYPE(RY); \
-    ++walked;                                                                              \
   }
-  MM_SLOT_WALK(MM_VISIT1)
+  for (u32 b_ = b0; b_ <= bl; ++b_) {
+    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue;
+    const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;
+    const uint4 q0 = S_[0], q1 = S_[1];
+    const u32 nAct_ = q0.x & 0xffffu;
+    u32 n_ = nAct_ + (q0.x >> 16);
+    if (reach_) n_ += slot_reach_count(P, q0.y);
+    const u32 first_ = (b_ == b0) ? 0u : nAct_;
+    walked_ += n_ - min(first_, n_);
+    int e0 = (int) q0.z + (int) (q0.w & REC_LEN_MASK), e1 = (int) q1.x + (int) (q1.y & REC_LEN_MASK),
+        e2 = (int) q1.z + (int) (q1.w & REC_LEN_MASK);
+    if ((q0.w | q1.y | q1.w) & REC_LONG) {
+      if (q0.w & REC_LONG) e0 = P.longEnd[q0.w & REC_LEN_MASK];
+      if (q1.y & REC_LONG) e1 = P.longEnd[q1.y & REC_LEN_MASK];
+      if (q1.w & REC_LONG) e2 = P.longEnd[q1.w & REC_LEN_MASK];
+    }
+    MM_TEST(q0.z, q0.w, e0, first_ == 0 && n_ > 0)
+    MM_TEST(q1.x, q1.y, e1, first_ <= 1 && n_ > 1)
+    MM_TEST(q1.z, q1.w, e2, first_ <= 2 && n_ > 2)
+    if (n_ > 3) {
+      const uint4 q2 = S_[2], q3 = S_[3];
+      int e3 = (int) q2.x + (int) (q2.y & REC_LEN_MASK), e4 = (int) q2.z + (int) (q2.w & REC_LEN_MASK),
+          e5 = (int) q3.x + (int) (q3.y & REC_LEN_MASK), e6 = (int) q3.z + (int) (q3.w & REC_LEN_MASK);
+      if ((q2.y | q2.w | q3.y | q3.w) & REC_LONG) {
+        if (q2.y & REC_LONG) e3 = P.longEnd[q2.y & REC_LEN_MASK];
+        if (q2.w & REC_LONG) e4 = P.longEnd[q2.w & REC_LEN_MASK];
+        if (q3.y & REC_LONG) e5 = P.longEnd[q3.y & REC_LEN_MASK];
+        if (q3.w & REC_LONG) e6 = P.longEnd[q3.w & REC_LEN_MASK];
+      }
+      MM_TEST(q2.x, q2.y, e3, first_ <= 3)
+      MM_TEST(q2.z, q2.w, e4, first_ <= 4 && n_ > 4)
+      MM_TEST(q3.x, q3.y, e5, first_ <= 5 && n_ > 5)
+      MM_TEST(q3.z, q3.w, e6, first_ <= 6 && n_ > 6)
+      if (n_ > 7) {
+        for (u32 k_ = max(7u, first_); k_ < n_; k_ += 4) {   // rare long lists: four loads in flight
+          const uint2 *F_ = P.flat + q0.y;
+          const uint2 r0 = F_[k_], r1 = F_[min(k_ + 1, n_ - 1)], r2 = F_[min(k_ + 2, n_ - 1)], r3 = F_[min(k_ + 3, n_ - 1)];
+          MM_VISIT1(r0.x, r0.y)
+          if (k_ + 1 < n_) MM_VISIT1(r1.x, r1.y)
+          if (k_ + 2 < n_) MM_VISIT1(r2.x, r2.y)
+          if (k_ + 3 < n_) MM_VISIT1(r3.x, r3.y)
+        }
+      }
+    }
+  }
 #undef MM_VISIT1
+#undef MM_TEST
+  walked += walked_;
   if (!hit) return 0;
   // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
   const int low = __ffsll((long long) hit) - 1;
@@ -649,7 +729,10 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   __syncthreads();
   u32 qinv = 0, qmax = 0, bigNh = 0;
   const u32 lane = threadIdx.x & 63;
-  u32 cHits = 0, cReads = 0, cUnique = 0, cAmb = 0, cMulti = 0, cUnas = 0;  // wave-uniform
+  // the six per-hit counters of addCount, two 16-bit fields to a register, kept per lane and summed once at the end (a lane sees at
+  // most 2^32 / (2048 x 256) = 8192 tuples): a ballot and a population count per counter and tuple was a tenth of the kernel's
+  // instructions, and the probe is bound by instruction issue (SQ_ACTIVE_INST_VALU = 73 % of the SIMDs' issue slots, round 2)
+  u32 cHU = 0, cAM = 0, cRN = 0;   // hits | unassigned << 16;  ambiguous | multiple << 16;  reads | unique << 16
   u32 walked = 0;
   const bool grouped_strategy = (P.strategy == MM_STRAT_DEFAULT);
   const bool ratio = (P.strategy == MM_STRAT_RATIO);
@@ -673,13 +756,20 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     // a multi-hit tuple below the caller's qid_lo: the launches (and, fused, the histogram's origin) were sized on that promise -
     // the batch is refused, and the tuple stays out of the pipeline so that nothing is written out of bounds
     if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
-    cHits += __popcll(__ballot(processed));
-    cUnas += __popcll(__ballot(processed && np == 0));
-    cAmb += __popcll(__ballot(processed && np > 1));
-    cUnique += __popcll(__ballot(processed && np == 1 && nh == 1));
-    cMulti += __popcll(__ballot(grouped));
-    if (hist) wave_hist_add<0>(sHist, min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u), grouped, true);   // (an id outside the promised range is an error anyway)
-    cReads += __popcll(__ballot(processed && !grouped));                           // mmannot.cpp:1737
+    cHU += (processed ? 1u : 0u) | ((processed && np == 0) ? 0x10000u : 0u);
+    cAM += ((processed && np > 1) ? 1u : 0u) | (grouped ? 0x10000u : 0u);
+    if (hist) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
+      const u64 gm = __ballot(grouped);
+      if (gm) {
+        const u32 d = min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u);   // (an id outside the promised range is an error anyway)
+        const int l0 = __ffsll((long long) gm) - 1;
+        const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
+        const u64 same = __ballot(grouped && d == d0);
+        if ((int) lane == l0) atomicAdd(&sHist[d0], (u32) __popcll(same));
+        else if (grouped && d != d0) atomicAdd(&sHist[d], 1u);
+      }
+    }
+    cRN += ((processed && !grouped) ? 1u : 0u) | ((processed && np == 1 && nh == 1) ? 0x10000u : 0u);   // mmannot.cpp:1737, 1668
     const bool counted = processed && !grouped && mask != 0 && P.strategy != MM_STRAT_RANDOM;   // mmannot.cpp:1704 (random: the caller decides)
     u32 key = NO_KEY, pay = GT_NO_SLOT;
     if (grouped) {
@@ -709,10 +799,15 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); bigNh |= __shfl_down(bigNh, off); }
     if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (bigNh) atomicOr(&sq[2], 1u); }
   }
-  if (lane == 0) {
-    atomicAdd(&sstat[MM_STAT_HITS], cHits); atomicAdd(&sstat[MM_STAT_READS], cReads);
-    atomicAdd(&sstat[MM_STAT_UNIQUE], cUnique); atomicAdd(&sstat[MM_STAT_AMBIGUOUS], cAmb);
-    atomicAdd(&sstat[MM_STAT_MULTIPLE], cMulti); atomicAdd(&sstat[MM_STAT_UNASSIGNED], cUnas);
+  {
+    u32 c[6] = {cHU & 0xFFFFu, cHU >> 16, cAM & 0xFFFFu, cAM >> 16, cRN & 0xFFFFu, cRN >> 16};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_down(c[k], off);
+    if (lane == 0) {
+      atomicAdd(&sstat[MM_STAT_HITS], c[0]); atomicAdd(&sstat[MM_STAT_UNASSIGNED], c[1]);
+      atomicAdd(&sstat[MM_STAT_AMBIGUOUS], c[2]); atomicAdd(&sstat[MM_STAT_MULTIPLE], c[3]);
+      atomicAdd(&sstat[MM_STAT_READS], c[4]); atomicAdd(&sstat[MM_STAT_UNIQUE], c[5]);
+    }
   }
   if (P.keep) {
     // total candidates visited (profiling aid)
@@ -1866,6 +1961,7 @@ struct mm_index {
   size_t n_slotBits = 0;
   int *d_longEnd = nullptr;
   int sshift = 0;
+  u32 reach = 0;
   size_t n_slots = 0, n_flat = 0;
   u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
   u64 lineMask[64];
@@ -2077,20 +2173,31 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       sN[c] = (u32) (maxEnd[c] >> sh) + 1; sBase[c] = (u32) ns; ns += sN[c];
       chrSlot[c] = make_uint2(sBase[c], sN[c]);
     }
-    std::vector<u32> nAct(ns, 0), nIv(ns, 0);
+    // Reach: a slot also lists, after its own records, the intervals that start within the first `reach` bases of the next bin, so
+    // that a read ending there (every short read that crosses a bin boundary) is served by the one slot of its start.  Without it
+    // nearly every wave walked a second bin for the tenth of its lanes that cross - a quarter of the probe's instructions.
+    const u32 W = 1u << sh, reach = std::min<u32>(W, 256u);
+    ix->reach = reach;
+    std::vector<u32> nAct(ns, 0), nIv(ns, 0), nOvh(ns, 0);
     for (size_t i = 0; i < n_iv; ++i) {
       if (end[i] < start[i]) continue;   // inverted zero-size intervals (e.g. -d 0) can only concern reads without CIGAR operations
       const int c = chr[i];
-      ++nIv[sBase[c] + ((u32) start[i] >> sh)];
-      const u32 b0 = ((u32) start[i] >> sh) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
+      const u32 bs = (u32) start[i] >> sh;
+      ++nIv[sBase[c] + bs];
+      if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) ++nOvh[sBase[c] + bs - 1];
+      const u32 b0 = bs + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
       for (u32 b = b0; b <= b1; ++b) ++nAct[sBase[c] + b];
     }
+    // flat: per slot one count record {nOvh, 0} and then act ++ iv ++ reach records; off[k] = the slot's first record, never below 8
+    // (the slot header's second word is the offset when the list is longer than the 7 inline records, the reach count otherwise)
     std::vector<u64> off(ns + 1, 0);
-    for (u64 k = 0; k < ns; ++k) off[k + 1] = off[k] + nAct[k] + nIv[k];
+    u64 running = 8;
+    for (u64 k = 0; k < ns; ++k) { off[k] = running + 1; running = off[k] + nAct[k] + nIv[k] + nOvh[k]; }
+    off[ns] = running;
     if (off[ns] >= 0xFFFFFFF0ull) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: slot lists too large; raise bin_shift"); }
-    flat.resize(off[ns] ? off[ns] : 1);
-    std::vector<u32> curA(ns), curI(ns);
-    for (u64 k = 0; k < ns; ++k) { curA[k] = (u32) off[k]; curI[k] = (u32) off[k] + nAct[k]; }
+    flat.assign(off[ns], make_uint2(0u, 0u));
+    std::vector<u32> curA(ns), curI(ns), curO(ns);
+    for (u64 k = 0; k < ns; ++k) { curA[k] = (u32) off[k]; curI[k] = curA[k] + nAct[k]; curO[k] = curI[k] + nIv[k]; flat[off[k] - 1] = make_uint2(nOvh[k], 0u); }
     for (size_t i = 0; i < n_iv; ++i) {
       if (end[i] < start[i]) continue;
       const int c = chr[i];
@@ -2102,24 +2209,27 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       if (len >= REC_LEN_MASK) { y |= REC_LONG; len = (u32) longEnd.size(); longEnd.push_back(end[i]); }
       y |= len | (t << REC_LEN_BITS) | ((okMinus ? 1u : 0u) << REC_OKBIT) | ((okPlus ? 1u : 0u) << (REC_OKBIT + 1));
       const uint2 rec = make_uint2((u32) start[i], y);
-      flat[curI[sBase[c] + ((u32) start[i] >> sh)]++] = rec;
-      const u32 b0 = ((u32) start[i] >> sh) + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
+      const u32 bs = (u32) start[i] >> sh;
+      flat[curI[sBase[c] + bs]++] = rec;
+      if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) flat[curO[sBase[c] + bs - 1]++] = rec;
+      const u32 b0 = bs + 1, b1 = std::min<u32>(((u32) end[i] + 1u) >> sh, sN[c] - 1);
       for (u32 b = b0; b <= b1; ++b) flat[curA[sBase[c] + b]++] = rec;
     }
     if (longEnd.size() >= REC_LEN_MASK) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: too many very long intervals"); }
     slots.assign(ns * 4, make_uint4(0u, 0u, 0u, 0u));
     slotBits.assign((ns + 31) / 32 + 1, 0u);
     for (u64 k = 0; k < ns; ++k) {
-      if (nAct[k] + nIv[k]) slotBits[k >> 5] |= 1u << (k & 31);
+      const u32 total = nAct[k] + nIv[k] + nOvh[k];
+      if (total) slotBits[k >> 5] |= 1u << (k & 31);
       u32 *w = (u32 *) &slots[k * 4];
       w[0] = nAct[k] | (nIv[k] << 16);
-      w[1] = (u32) off[k];
+      w[1] = total <= 7 ? nOvh[k] : (u32) off[k];
       if (nAct[k] > 0xFFFFu || nIv[k] > 0xFFFFu) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: more than 65535 intervals in one bin; lower bin_shift"); }
-      const u32 n = std::min<u32>(nAct[k] + nIv[k], 7u);
+      const u32 n = std::min<u32>(total, 7u);
       for (u32 r = 0; r < n; ++r) { w[2 + 2 * r] = flat[off[k] + r].x; w[3 + 2 * r] = flat[off[k] + r].y; }
     }
     u64 nonEmpty = 0;
-    for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k]) ? 1 : 0;
+    for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k] + nOvh[k]) ? 1 : 0;
     if ((double) (ns - nonEmpty) < 0.42 * (double) ns) slotBits.clear();
     // (Measured and rejected, round 2: storing the non-empty bins only - slot found through a running count kept beside each bitmap
     // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
@@ -2299,7 +2409,7 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   const mm_index *ix = c->ix;
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
-  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift;
+  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
   P.useSlots = getenv("MMANNOT_AMD_FULL_INDEX_ONLY") ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
