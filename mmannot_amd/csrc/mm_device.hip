@@ -678,11 +678,11 @@ __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewe
 
 // scan() + getFirst() of one tuple: read strand from -s (strandF / strandR / strandU, mmannot.cpp:836-844), then the index
 template <int OVL>
-__device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, const uint2 *chrSlot, const u64 *sLine, const int4 a, u32 &walked) {
+__device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, bool useSlots, const uint2 *chrSlot, const u64 *sLine, const int4 a, u32 &walked) {
   const int rec_strand = a.z & 1;
   const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
   // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
-  return (P.useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
+  return (useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
                                     : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
 }
 
@@ -705,7 +705,11 @@ __global__ __launch_bounds__(256) void k_expand12(const u32 *__restrict__ pk, in
 //     LDS-privatised table (default with NH<=1, unique), or its table slot recorded for the
 //     ordered -y ratio accumulation, or
 //   * the multi-hit branch (mmannot.cpp:1669-1702): set + name id recorded for k_chunk_default.
-template <int OVL>
+// what a k_probe instance takes for granted (the general one reads everything from its arguments)
+enum { PV_GENERAL = 0, PV_COUNT = 1,        // per-hit counting only: default with the single-hit promise, unique
+       PV_GROUPS_HIST = 2, PV_GROUPS = 3,   // default with multi-hit records, with / without the fused bucket histogram
+       PV_RATIO = 4 };
+template <int OVL, int VAR>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
                                                int single, u32 qlo, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
                                                u32 *__restrict__ info, GlobalTable G, u64 *__restrict__ stats,
@@ -721,11 +725,18 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   __shared__ uint2 sChr[MM_LDS_CHR]; // keep them in LDS instead of gathering them from global memory
   if (threadIdx.x < 64) sLine[threadIdx.x] = P.lineMask[threadIdx.x];
   for (u32 c = threadIdx.x; c < min(P.nchr, (u32) MM_LDS_CHR); c += blockDim.x) sChr[c] = P.chrSlot[c];
-  const uint2 *chrSlot = (P.nchr <= (u32) MM_LDS_CHR) ? sChr : P.chrSlot;
+  // VAR != 0: what the launch knows is a compile-time constant here (see the PV_* list) - each run-time flag of the general kernel
+  // (VAR == PV_GENERAL) costs a pair of scalar registers held across the loop, and the kernel already keeps some in VGPR lanes
+  constexpr bool V = VAR != PV_GENERAL;
+  const uint2 *chrSlot = (V || P.nchr <= (u32) MM_LDS_CHR) ? sChr : P.chrSlot;
+  const bool useHist = V ? (VAR == PV_GROUPS_HIST) : (hist != nullptr);
+  const bool haveKey = V ? (VAR != PV_COUNT) : (gkey != nullptr);
+  const bool keepSets = V ? false : (hm != nullptr && P.keep);
+  const bool useSlots = V ? true : (P.useSlots != 0);
   lds_table_init(T);
   if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
   if (threadIdx.x < 3) sq[threadIdx.x] = 0;
-  if (hist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) sHist[d] = 0;
+  if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) sHist[d] = 0;
   __syncthreads();
   u32 qinv = 0, qmax = 0, bigNh = 0;
   const u32 lane = threadIdx.x & 63;
@@ -734,10 +745,12 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   // instructions, and the probe is bound by instruction issue (SQ_ACTIVE_INST_VALU = 73 % of the SIMDs' issue slots, round 2)
   u32 cHU = 0, cAM = 0, cRN = 0;   // hits | unassigned << 16;  ambiguous | multiple << 16;  reads | unique << 16
   u32 walked = 0;
-  const bool grouped_strategy = (P.strategy == MM_STRAT_DEFAULT);
-  const bool ratio = (P.strategy == MM_STRAT_RATIO);
-  const size_t first = hist ? (size_t) blockIdx.x * RS_TILE : (size_t) blockIdx.x * blockDim.x;
-  const size_t last = hist ? min(n, first + (size_t) RS_TILE) : n, step = hist ? (size_t) blockDim.x : (size_t) gridDim.x * blockDim.x;
+  const bool grouped_strategy = V ? (VAR == PV_GROUPS || VAR == PV_GROUPS_HIST) : (P.strategy == MM_STRAT_DEFAULT);
+  const bool ratio = V ? (VAR == PV_RATIO) : (P.strategy == MM_STRAT_RATIO);
+  const bool uniqueOnly = (V && VAR != PV_COUNT) ? false : (P.strategy == MM_STRAT_UNIQUE);
+  const bool randomStrategy = V ? false : (P.strategy == MM_STRAT_RANDOM);
+  const size_t first = useHist ? (size_t) blockIdx.x * RS_TILE : (size_t) blockIdx.x * blockDim.x;
+  const size_t last = useHist ? min(n, first + (size_t) RS_TILE) : n, step = useHist ? (size_t) blockDim.x : (size_t) gridDim.x * blockDim.x;
   for (size_t base = first; base < last; base += step) {
     const size_t i = base + threadIdx.x;
     const bool valid = i < last;
@@ -748,9 +761,9 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       nh = tuple_nh((u32) a.z, i, big, nbig, G.err);
       if (single && nh > 1) { atomicCAS(G.err, 0u, (u32) ERR_SINGLE_HIT); nh = 1; }   // MM_BATCH_SINGLE_HIT was a promise
     }
-    const bool processed = valid && !(P.strategy == MM_STRAT_UNIQUE && nh != 1);  // mmannot.cpp:1773
+    const bool processed = valid && !(uniqueOnly && nh != 1);  // mmannot.cpp:1773
     u64 mask = 0;
-    if (processed) mask = probe_tuple<OVL>(P, chrSlot, sLine, a, walked);
+    if (processed) mask = probe_tuple<OVL>(P, useSlots, chrSlot, sLine, a, walked);
     const int np = __popcll(mask);
     bool grouped = processed && grouped_strategy && nh > 1;
     // a multi-hit tuple below the caller's qid_lo: the launches (and, fused, the histogram's origin) were sized on that promise -
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
     cHU += (processed ? 1u : 0u) | ((processed && np == 0) ? 0x10000u : 0u);
     cAM += ((processed && np > 1) ? 1u : 0u) | (grouped ? 0x10000u : 0u);
-    if (hist) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
+    if (useHist) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
       const u64 gm = __ballot(grouped);
       if (gm) {
         const u32 d = min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u);   // (an id outside the promised range is an error anyway)
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       }
     }
     cRN += ((processed && !grouped) ? 1u : 0u) | ((processed && np == 1 && nh == 1) ? 0x10000u : 0u);   // mmannot.cpp:1737, 1668
-    const bool counted = processed && !grouped && mask != 0 && P.strategy != MM_STRAT_RANDOM;   // mmannot.cpp:1704 (random: the caller decides)
+    const bool counted = processed && !grouped && mask != 0 && !randomStrategy;   // mmannot.cpp:1704 (random: the caller decides)
     u32 key = NO_KEY, pay = GT_NO_SLOT;
     if (grouped) {
       key = (u32) a.w;
@@ -788,14 +801,14 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       else pay = slot_of_set(T, G, mask) & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
     }
     if (valid) {
-      if (gkey) {
+      if (haveKey) {
         gkey[i] = key;                       // read again right away by the first sort pass: keep these cacheable
         gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
       }
-      if (hm && P.keep) st_stream(hm + i, processed ? mask : ~0ull);   // (parity / side channels only, see k_probe_sets)
+      if (keepSets) st_stream(hm + i, processed ? mask : ~0ull);   // (parity / side channels only, see k_probe_sets)
     }
   }
-  if (grouped_strategy && gkey) {
+  if (grouped_strategy && haveKey) {
     for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); bigNh |= __shfl_down(bigNh, off); }
     if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (bigNh) atomicOr(&sq[2], 1u); }
   }
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       atomicAdd(&sstat[MM_STAT_READS], c[4]); atomicAdd(&sstat[MM_STAT_UNIQUE], c[5]);
     }
   }
-  if (P.keep) {
+  if (!V && P.keep) {
     // total candidates visited (profiling aid)
     u32 w = walked;
     for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
@@ -817,8 +830,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   }
   __syncthreads();
   if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
-  if (hist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
-  if (grouped_strategy && gkey && threadIdx.x == 0) {
+  if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
+  if (grouped_strategy && haveKey && threadIdx.x == 0) {
     if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
     if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
     if (sq[2]) atomicOr(&info[INFO_BIGNH], 1u);
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_sets(const ProbePar
   u32 walked = 0;
   for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
     const int4 a = ld_stream(aln + i);
-    if (tuple_nh((u32) a.z, i, big, nbig, err) > 1) hm[i] = probe_tuple<OVL>(P, chrSlot, sLine, a, walked);
+    if (tuple_nh((u32) a.z, i, big, nbig, err) > 1) hm[i] = probe_tuple<OVL>(P, P.useSlots != 0, chrSlot, sLine, a, walked);
   }
 }
 
@@ -2581,16 +2594,30 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
   PhaseTimer t(c, MM_PHASE_PROBE);
-  switch (c->opt.overlap_mode) {
-    case MM_OVL_INCLUSION:
-      hipLaunchKernelGGL(k_probe<MM_OVL_INCLUSION>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
-      break;
-    case MM_OVL_PC:
-      hipLaunchKernelGGL(k_probe<MM_OVL_PC>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
-      break;
-    default:
-      hipLaunchKernelGGL(k_probe<MM_OVL_NT>, dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk);
+  // the instance that takes this launch's constants for granted, or the general one (side outputs, -y random, an index without slots,
+  // more chromosomes than the LDS table holds; MMANNOT_AMD_GENERAL_PROBE=1 forces it for A/B measurements and tests)
+  int var = PV_GENERAL;
+  if (P.useSlots && P.nchr <= (u32) MM_LDS_CHR && !P.keep && P.strategy != MM_STRAT_RANDOM && !getenv("MMANNOT_AMD_GENERAL_PROBE"))
+    var = ratio ? PV_RATIO : ((dflt && need_groups) ? (fuse_hist ? PV_GROUPS_HIST : PV_GROUPS) : PV_COUNT);
+#define MM_LAUNCH_PROBE(OVL, VAR)                                                                                                  \
+  hipLaunchKernelGGL((k_probe<OVL, VAR>), dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big,    \
+                     single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk,                   \
+                     fuse_hist ? c->d_hist : (u32 *) nullptr, nblk)
+#define MM_LAUNCH_PROBE_VAR(OVL)                                        \
+  switch (var) {                                                        \
+    case PV_COUNT: MM_LAUNCH_PROBE(OVL, PV_COUNT); break;               \
+    case PV_GROUPS_HIST: MM_LAUNCH_PROBE(OVL, PV_GROUPS_HIST); break;   \
+    case PV_GROUPS: MM_LAUNCH_PROBE(OVL, PV_GROUPS); break;             \
+    case PV_RATIO: MM_LAUNCH_PROBE(OVL, PV_RATIO); break;               \
+    default: MM_LAUNCH_PROBE(OVL, PV_GENERAL);                          \
   }
+  switch (c->opt.overlap_mode) {
+    case MM_OVL_INCLUSION: MM_LAUNCH_PROBE_VAR(MM_OVL_INCLUSION) break;
+    case MM_OVL_PC: MM_LAUNCH_PROBE_VAR(MM_OVL_PC) break;
+    default: MM_LAUNCH_PROBE_VAR(MM_OVL_NT)
+  }
+#undef MM_LAUNCH_PROBE_VAR
+#undef MM_LAUNCH_PROBE
   }
   bool huge_nh = false;                                  // an NH >= 65535 can only come through the side list
   for (size_t k = 0; k < n_big && !huge_nh; ++k) huge_nh = big[k].nh >= 0xFFFFu;

@@ -64,6 +64,8 @@ def test_reference_golden(gpu_lib, name, batches):
     assert r["stderr"] in c["stderr"]
     m = r["hit"][r["hit"] != ALL1]
     assert len(m) == len(HITMASKS[name]) and (m == HITMASKS[name]).all()
+    r = run_gpu(mm, cfg, ix, READS, overlap=o["overlap"], strandedness=o["strandedness"], strategy=o["strategy"], batches=batches, keep=False)
+    assert r["table"] == c["table"] and r["stderr"] in c["stderr"]   # the instance compiled for the launch (no side output)
 
 
 SYNTH = [(seed, l, s, y) for seed in (1, 2, 3) for l in (-1.0, 0.0, 0.4, 0.83, 1.0, 25.0) for s in ("U", "F", "R")
@@ -88,6 +90,21 @@ def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
             got = dict(zip(r["masks"].tolist(), r["sums"].view(np.uint64).tolist()))
             want = dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
             assert got == want
+    # without the per-hit side output k_probe runs the instance compiled for the launch (counting only / multi-hit records with or
+    # without the fused histogram / ratio) instead of the general one: same table, same counters, same sums
+    want_table = oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+    for batches, shift in ((1, 0), (4, 9)):
+        r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s, strategy=y, batches=batches, bin_shift=shift, keep=False)
+        assert r["stats"] == ref.stats and r["table"] == want_table, f"specialised instance differs (batches={batches}, shift={shift})"
+        if y == "ratio":
+            assert dict(zip(r["masks"].tolist(), r["sums"].view(np.uint64).tolist())) == dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
+    if seed == 1 and s == "U":   # and the general instance forced onto the same launch
+        os.environ["MMANNOT_AMD_GENERAL_PROBE"] = "1"
+        try:
+            r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s, strategy=y, batches=2, keep=False)
+        finally:
+            del os.environ["MMANNOT_AMD_GENERAL_PROBE"]
+        assert r["stats"] == ref.stats and r["table"] == want_table
 
 
 def test_name_grouped_input(gpu_lib, oracle):
