@@ -560,6 +560,8 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
   const int low = __ffsll((long long) hit) - 1;
   const u64 cand = hit & lineMask[low];
   if ((cand & (cand - 1)) == 0) return cand;
+  // inclusion counts every passing interval as overlap 1, and only "upstream" / "downstream" elements have a distance: all tie
+  if (OVL == MM_OVL_INCLUSION && !(cand & (P.elemUp | P.elemDown))) return cand;
   // pass 2 (several elements of the winning line were hit): each element's last writer (overlap, distance), then max
   // overlap, then min distance, ties kept (mmannot.cpp:1023-1028, 1049-1075); the slot lines are in L1 by now
   u64 sel = 0;
@@ -627,6 +629,8 @@ __device__ __forceinline__ u64 probe_one(const ProbeParams &P, int s, int e, u32
   const int low = __ffsll((long long) hit) - 1;
   const u64 cand = hit & P.lineMask[low];
   if ((cand & (cand - 1)) == 0) return cand;
+  // inclusion counts every passing interval as overlap 1, and only "upstream" / "downstream" elements have a distance: all tie
+  if (OVL == MM_OVL_INCLUSION && !(cand & (P.elemUp | P.elemDown))) return cand;
   // several elements of the winning line were hit: max overlap, then min distance, ties kept
   u64 sel = 0;
   u32 maxO = 0, minD = 0;
