@@ -95,7 +95,10 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MM_BENCH_FORCE_DIST=1: the multi-rank code path (process group, warm-up, merge collectives, chain) with whatever world size the
+    # launcher gave, also 1 - so that the RCCL backend can be exercised on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("MM_BENCH_FORCE_DIST"))
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -116,7 +119,7 @@ def main():
     info = index.info()
     stream = torch.cuda.current_stream().cuda_stream
     ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy, stream=stream,
-                     defer_ratio=(strategy == "ratio" and world > 1))
+                     defer_ratio=(strategy == "ratio" and multi))
 
     # ---------------- inputs: W+K batches per rank (rank-local stream, rank-local read-name ids)
     B = 1 << args.batch_log2
@@ -204,7 +207,7 @@ def main():
         ctr.sync()
         # HIP events around the probe launches and the copies only: every recorded event costs a few microseconds of stream time
         ctr.set_profiling(2)
-        if world > 1:
+        if multi:
             # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
             if strategy == "ratio":
                 warm_up(device=comm_dev, p2p=True)
@@ -217,17 +220,17 @@ def main():
             step(s)
         ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
         stats = ctr.stats()
-        if strategy == "ratio" and world > 1:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
+        if strategy == "ratio" and multi:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
             masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "1")))
         else:
             masks, sums = ctr.getCounts()
             masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         t1 = time.perf_counter()
         el = torch.tensor([t1 - t0], dtype=torch.float64, device=comm_dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         phases = ctr.phase_ms()
         ctr.set_profiling(0)
@@ -256,7 +259,7 @@ def main():
 
     # phase breakdown: resident batches once more on a cleared context, every phase bracketed by events (not part of any rate)
     n_phase = min(args.steps, 10)
-    if strategy == "ratio" and world > 1:      # (deferred accumulation: its merge phase runs inside the rank-to-rank chain)
+    if strategy == "ratio" and multi:      # (deferred accumulation: its merge phase runs inside the rank-to-rank chain)
         phases_all = (res_dev or res_host)[1]
         n_phase = args.steps
     else:
@@ -341,7 +344,7 @@ def main():
                 out["cpu_baseline"] = port
         print(json.dumps(out))
     ctr.close(); index.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -10,6 +10,7 @@ summed across shards.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import numpy as np
@@ -17,10 +18,18 @@ import torch
 import torch.distributed as dist
 
 
+def _alone(group) -> bool:
+    """No exchange to make: no process group, or a group of one (unless MM_BENCH_FORCE_DIST asks for the collectives anyway - the
+    way to run the RCCL calls of this module on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not os.environ.get("MM_BENCH_FORCE_DIST")
+
+
 def warm_up(device=None, group=None, p2p: bool = False) -> None:
     """One tiny call of every collective the merge uses (and, for the -y ratio chain, a send/recv round along the ranks):
     RCCL sets its channels and kernels up on first use, which would otherwise land inside a timed region."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _alone(group):
         return
     ws, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
@@ -38,7 +47,7 @@ def warm_up(device=None, group=None, p2p: bool = False) -> None:
 
 def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], device=None, group=None) -> Tuple[np.ndarray, np.ndarray, Dict[str, int]]:
     """masks uint64[n], sums float64[n] (integral), stats dict -> merged (masks, sums, stats), identical on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _alone(group):
         return masks, sums, stats
     ws = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
@@ -77,7 +86,7 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunk
     (DESIGN.md section 5): with rows travelling through the host on every hop the fixed cost per hop outweighs the overlap, so
     the default stays 1.  Returns (masks, sums, stats) identical on every rank."""
     from .api import row_chunk
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _alone(group):
         counter.resolve_ratio()
         m, s = counter.getCounts()
         return m, s, stats

@@ -77,3 +77,19 @@ def test_two_ranks_strong_scaling_gloo(gpu_lib):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads(_json_lines(p.stdout.decode())[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["stats"]["nHits"] == 4 * (1 << 20) and d["config"]["batch_alignments_per_gpu"] == 1 << 19
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload", ["c3", "c5"])
+def test_rccl_backend_group_of_one(gpu_lib, workload):
+    """The default backend ("nccl" = RCCL) through the multi-rank code path - process group bound to the device, warm-up, the merge's
+    all_gather / all_reduce / broadcast on device tensors, the ratio chain's end - with the one GPU this box has (MM_BENCH_FORCE_DIST)."""
+    env = dict(os.environ, MM_BENCH_FORCE_DIST="1")
+    env.pop("MM_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch-log2", "20",
+                        "--workload", workload, "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads(_json_lines(p.stdout.decode())[0])
+    assert d["n_gpus"] == 1 and d["stats"]["nHits"] == 4 * (1 << 20) and d["table_rows"] > 0
