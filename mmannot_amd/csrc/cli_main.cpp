@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -99,9 +101,11 @@ struct GlibcRand {
 // library's copy stream drains the two submitted before it (a host buffer is free again once the second-next
 // mm_annotate_batch has returned), so H2D copies, kernels and decoding overlap and nothing waits per batch.
 struct Staging {
-  // tuples per batch; MM_CLI_BATCH overrides it (tests: many small batches through the asynchronous pipeline)
+  // tuples per batch (2^21: the decoder, not the device, sets the pace of a run from files, and hands over smaller batches sooner -
+  // measured on a 16.8 M-record BAM against 2^22: 0.53 s instead of 0.60); MM_CLI_BATCH overrides it (tests: many small batches
+  // through the asynchronous pipeline)
   static size_t batch() {
-    static const size_t b = [] { const char *e = getenv("MM_CLI_BATCH"); const long v = e ? atol(e) : 0; return v >= 64 ? (size_t) v : (size_t) 1 << 22; }();
+    static const size_t b = [] { const char *e = getenv("MM_CLI_BATCH"); const long v = e ? atol(e) : 0; return v >= 64 ? (size_t) v : (size_t) 1 << 21; }();
     return b;
   }
   mm_aln *buf[3] = {nullptr, nullptr, nullptr};
@@ -257,6 +261,15 @@ int main(int argc, char **argv) {
   double t_annot = 0, t_index = 0, t_decode = 0, t_device = 0, t_host = 0;
   uint64_t n_records = 0;
   const auto t_start = now();
+  const bool teardown = getenv("MM_CLI_TEARDOWN") && *getenv("MM_CLI_TEARDOWN") && *getenv("MM_CLI_TEARDOWN") != '0';   // (see the end of main)
+  // The device side needs no annotation to come up: the HIP runtime's start and the pinned staging buffers of the plain path (one
+  // device, files one after the other) are requested now, on a thread of their own, while the GTF is parsed.
+  const bool plain_path = devices.size() <= 1 && (n_threads <= 1 || n_inputs <= 1);
+  std::unique_ptr<Staging> stg_plain;
+  std::future<void> bringup = std::async(std::launch::async, [&]() {
+    if (plain_path) stg_plain.reset(new Staging);
+    else mm_host_free(mm_host_alloc(4096));
+  });
   mm_annotation *an = nullptr;
   if (mm_annotation_load(&an, config.c_str(), gtf.c_str(), upstream, downstream) != MM_OK) {
     std::cerr << mm_annotation_error() << std::endl;
@@ -264,6 +277,7 @@ int main(int argc, char **argv) {
   }
   std::cerr << mm_annotation_log(an);
   t_annot = secs(t_start, now());
+  bringup.get();
   // devices: --device d (one), --devices a,b,.. (several); with -t n > 1 and neither given, every visible device takes files
   if (devices.empty()) {
     if (device_given || n_threads <= 1 || n_inputs <= 1) devices.push_back(device);
@@ -272,17 +286,45 @@ int main(int argc, char **argv) {
   // several devices for ONE input file: its reads are sharded over them (not with the sequential side channels -m / -M / -y random)
   const bool shard_one_input = n_inputs == 1 && devices.size() > 1 && !host_book;
   if (!shard_one_input && devices.size() > n_inputs) devices.resize(std::max<size_t>(1, n_inputs));
-  std::vector<mm_index *> indices;
-  { const auto t0 = now();
-  for (int d : devices) {
-    mm_index *ix = nullptr;
-    if (mm_index_from_annotation(&ix, an, d, 0) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
-    indices.push_back(ix);
-  }
-  t_index = secs(t0, now()); }
   mm_options opt;
   opt.overlap_mode = overlap < 0.0 ? MM_OVL_INCLUSION : (overlap < 1.0 ? MM_OVL_PC : MM_OVL_NT);
   opt.overlap_value = overlap; opt.strandedness = strandedness; opt.strategy = strategy; opt.keep_hit_masks = host_book ? 1 : 0; opt.defer_ratio = 0;
+  std::vector<mm_index *> indices;
+  // plain path: index and context are built on a thread of their own while the first batch of reads is decoded (the decoder needs the
+  // annotation's chromosome names only); the first mm_annotate_batch waits for them
+  const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t) n_threads, n_inputs));
+  const bool late_device = plain_path && devices.size() == 1 && !shard_one_input && n_workers == 1;
+  mm_ctx *plain_ctx = nullptr;
+  std::string late_err;
+  std::future<void> late_job;
+  auto build_indices = [&]() -> bool {
+    const auto t0 = now();
+    for (int d : devices) {
+      mm_index *ix = nullptr;
+      if (mm_index_from_annotation(&ix, an, d, 0) != MM_OK) { late_err = mm_last_error(); return false; }
+      indices.push_back(ix);
+    }
+    t_index = secs(t0, now());
+    return true;
+  };
+  if (late_device) {
+    late_job = std::async(std::launch::async, [&]() {
+      if (!stg_plain || !stg_plain->ok()) { late_err = "mm_host_alloc: pinned staging buffers not available"; return; }
+      if (!build_indices()) return;
+      if (mm_ctx_create(&plain_ctx, indices[0], &opt, nullptr) != MM_OK) { late_err = mm_last_error(); plain_ctx = nullptr; }
+    });
+  } else if (!build_indices()) { std::cerr << "mmannot-amd: " << late_err << std::endl; return EXIT_FAILURE; }
+  double t_wait_device = 0;
+  // the plain path's context, waiting for the background build the first time (nullptr: it failed; the message is printed here)
+  std::function<mm_ctx *()> late_ctx = [&]() -> mm_ctx * {
+    if (late_job.valid()) {
+      const auto t0 = now();
+      late_job.get();
+      t_wait_device = secs(t0, now());
+      if (!plain_ctx) std::cerr << "mmannot-amd: " << late_err << std::endl;
+    }
+    return plain_ctx;
+  };
   const int32_t E = mm_annotation_n_elements(an);
   std::vector<std::string> elem_names;
   for (int32_t e = 0; e < E; ++e) elem_names.push_back(mm_annotation_element_name(an, e));
@@ -336,7 +378,8 @@ int main(int argc, char **argv) {
   };
   auto process_file = [&](size_t fi, mm_ctx *ctx, std::ostream &err, Staging &stg, RandomState &rnd) -> int {
     std::vector<uint64_t> &hm = stg.hm;
-    if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+    // ctx == nullptr: the plain path's context, still being built when the first file is opened (late_ctx)
+    if (ctx && mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
     if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
@@ -392,6 +435,11 @@ int main(int argc, char **argv) {
       if (rc != MM_OK) { err << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
       const auto t1 = now();
       { std::lock_guard<std::mutex> lk(table_mu); t_decode += secs(t0, t1); n_records += n; }
+      if (!ctx) {   // (before the end-of-file test: an empty file still needs its context for the report)
+        ctx = late_ctx();
+        if (!ctx) { mm_reader_close(rd); return EXIT_FAILURE; }
+        if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+      }
       if (n == 0) break;
       // asynchronous: the copy and the kernels of this batch run while the next one is decoded; only the sequential side
       // channels (-m / -M / -y random), which read per-hit results back, wait for the batch
@@ -572,7 +620,6 @@ int main(int argc, char **argv) {
     mm_reader_close(rd);
     return 0;
   };
-  const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t) n_threads, n_inputs));
   int rc_all = 0;
   if (shard_one_input) {
     mm_options mopt = opt;
@@ -586,13 +633,20 @@ int main(int argc, char **argv) {
     rc_all = process_file_multi(0, ctxs, std::cerr);
     for (mm_ctx *c : ctxs) mm_ctx_destroy(c);
   } else if (n_workers == 1) {
-    Staging stg;
     RandomState rnd;
-    mm_ctx *ctx = nullptr;
-    if (!stg.ok()) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
-    if (mm_ctx_create(&ctx, indices[0], &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
-    for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, ctx, std::cerr, stg, rnd);
-    mm_ctx_destroy(ctx);
+    if (late_device) {
+      for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, fi == 0 ? nullptr : plain_ctx, std::cerr, *stg_plain, rnd);
+      if (late_job.valid()) late_job.get();          // (the first file failed before it needed the device)
+      if (plain_ctx && teardown) mm_ctx_destroy(plain_ctx);
+    } else {
+      std::unique_ptr<Staging> own(stg_plain ? nullptr : new Staging);
+      Staging &stg = stg_plain ? *stg_plain : *own;
+      mm_ctx *ctx = nullptr;
+      if (!stg.ok()) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+      if (mm_ctx_create(&ctx, indices[0], &opt, nullptr) != MM_OK) { std::cerr << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
+      for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, ctx, std::cerr, stg, rnd);
+      if (teardown) mm_ctx_destroy(ctx);
+    }
   } else {
     // -t n: the reference runs n threads over the input files (mmannot.cpp:2117-2143); here n files are in flight, each on its
     // own context, spread over the devices
@@ -636,14 +690,28 @@ int main(int argc, char **argv) {
   out.flush();
   if (read_stats) read_stats_out.close();
   if (interval_stats) interval_stats_out.close();
-  for (mm_index *ix : indices) mm_index_destroy(ix);
-  mm_annotation_free(an);
   std::cerr << "Successfully done." << std::endl;
+  // Everything is written.  Tearing the process down piece by piece (three pinned buffers, the index, the annotation's strings, the
+  // HIP runtime's own exit handlers) took a fifth of a second - a quarter of a 17 M-record run - for memory the kernel reclaims
+  // anyway, so the process ends here; MM_CLI_TEARDOWN=1 keeps the orderly exit (leak checkers, sanitizers).
+  if (teardown) {
+    for (mm_index *ix : indices) mm_index_destroy(ix);
+    mm_annotation_free(an);
+  }
   if (timing) {
     const double total = secs(t_start, now());
-    t_host = total - t_annot - t_index - t_decode - t_device;
-    fprintf(stderr, "[mmannot-amd timing] total %.3f s: annotation %.3f, index %.3f, waiting for the decoder %.3f, device %.3f, other host %.3f; %llu records, %.2f M records/s\n",
-            total, t_annot, t_index, t_decode, t_device, t_host, (unsigned long long) n_records, n_records / total / 1e6);
+    // (plain path: index and context are built beside the first batch's decoding; only what the main thread still waited for is its own)
+    t_host = total - t_annot - (late_device ? t_wait_device : t_index) - t_decode - t_device;
+    char ix[96];
+    if (late_device) snprintf(ix, sizeof ix, "index %.3f (beside the first batch; waited %.3f for index + context)", t_index, t_wait_device);
+    else snprintf(ix, sizeof ix, "index %.3f", t_index);
+    fprintf(stderr, "[mmannot-amd timing] total %.3f s: annotation %.3f, %s, waiting for the decoder %.3f, device %.3f, other host %.3f; %llu records, %.2f M records/s\n",
+            total, t_annot, ix, t_decode, t_device, t_host, (unsigned long long) n_records, n_records / total / 1e6);
+  }
+  if (!teardown) {
+    if (!output.empty()) of.close();
+    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    std::_Exit(0);
   }
   return 0;
 }

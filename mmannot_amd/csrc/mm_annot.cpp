@@ -341,6 +341,7 @@ extern "C" int mm_annotation_load(mm_annotation **out, const char *config_path, 
   std::unordered_map<std::string, size_t> gene_of;  // any id (gene, transcript, ...) -> gene index; reset per chromosome block
   std::unordered_set<std::string> unused;
   std::vector<GeneModel> genes;
+  genes.reserve(1 << 16);
   std::string line, chromosome;
   uint32_t chr_id = 0xFFFFFFFFu;
   uint64_t cpt = 0;
@@ -429,10 +430,13 @@ extern "C" int mm_annotation_load(mm_annotation **out, const char *config_path, 
   // gene -> typed intervals, in the reference's emission order
   std::vector<IvOut> &iv = A->iv;
   auto push = [&](const GeneModel &g, uint64_t s, uint64_t e, long t, const char *suffix) {
-    IvOut o; o.chr = g.chr; o.start = s; o.end = e; o.type = (uint32_t) t; o.strand = (uint8_t) g.strand; o.id = g.id + suffix;
-    iv.push_back(o);
+    iv.emplace_back();
+    IvOut &o = iv.back();
+    o.chr = g.chr; o.start = s; o.end = e; o.type = (uint32_t) t; o.strand = (uint8_t) g.strand;
+    o.id.reserve(g.id.size() + 12); o.id = g.id; o.id += suffix;
   };
   std::vector<Seg> piece, u_left, u_right;
+  iv.reserve(genes.size() * 6);
   for (GeneModel &g : genes) {
     std::sort(g.exons.begin(), g.exons.end(), [](const Seg &a, const Seg &b) { return a.s < b.s; });
     if (g.exons.empty()) g.exons.push_back(g.hull);
@@ -476,7 +480,18 @@ extern "C" int mm_annotation_load(mm_annotation **out, const char *config_path, 
   // The reference sorts with std::sort on (chromosome, start) only (mmannot.cpp:697-699, 1267): the order it
   // leaves equal-start intervals in is observable (last writer wins).  Same libstdc++ algorithm, same input
   // order, same comparator => same permutation.
-  std::sort(iv.begin(), iv.end(), [](const IvOut &a, const IvOut &b) { return a.chr < b.chr || (a.chr == b.chr && a.start < b.start); });
+  // (sorted through 16-byte keys and then permuted: the algorithm's comparisons and moves do not depend on what else an element
+  // carries, and moving the records themselves - each owns its id string - was a fifth of the loading time)
+  {
+    struct Key { uint32_t chr; uint32_t idx; uint64_t start; };
+    std::vector<Key> keys(iv.size());
+    for (size_t i = 0; i < iv.size(); ++i) { keys[i].chr = iv[i].chr; keys[i].idx = (uint32_t) i; keys[i].start = iv[i].start; }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.chr < b.chr || (a.chr == b.chr && a.start < b.start); });
+    std::vector<IvOut> sorted;
+    sorted.reserve(iv.size());
+    for (const Key &k : keys) sorted.push_back(std::move(iv[k.idx]));
+    iv.swap(sorted);
+  }
   if (iv.empty()) {
     g_annot_err = "Error, the annotation file has not been parsed properly!\nPlease check that your annotation file is not empty, and that your configuration file matches your annotation file.\nIf you have trouble designing a configuration file, please use the companion tool 'createConfigFile'.";
     g_annot_err = A->log + g_annot_err;  // the log written so far comes first, as on the reference's stderr
