@@ -309,7 +309,7 @@ int main(int argc, char **argv) {
   };
   if (late_device) {
     late_job = std::async(std::launch::async, [&]() {
-      if (!stg_plain || !stg_plain->ok()) { late_err = "mm_host_alloc: pinned staging buffers not available"; return; }
+      if (!stg_plain || !stg_plain->ok()) { late_err = "cannot allocate pinned host memory (is there a HIP device?)"; return; }
       if (!build_indices()) return;
       if (mm_ctx_create(&plain_ctx, indices[0], &opt, nullptr) != MM_OK) { late_err = mm_last_error(); plain_ctx = nullptr; }
     });
@@ -635,6 +635,7 @@ int main(int argc, char **argv) {
   } else if (n_workers == 1) {
     RandomState rnd;
     if (late_device) {
+      if (!stg_plain || !stg_plain->ok()) { late_ctx(); return EXIT_FAILURE; }   // (no device: the background job says why)
       for (size_t fi = 0; fi < n_inputs && !rc_all; ++fi) rc_all = process_file(fi, fi == 0 ? nullptr : plain_ctx, std::cerr, *stg_plain, rnd);
       if (late_job.valid()) late_job.get();          // (the first file failed before it needed the device)
       if (plain_ctx && teardown) mm_ctx_destroy(plain_ctx);

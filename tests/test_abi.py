@@ -63,3 +63,21 @@ def test_no_gpu_fails_loudly():
         assert e.code == 2
     else:
         raise AssertionError("index creation succeeded without a GPU")
+
+
+def test_cli_without_gpu_says_so():
+    """The binary brings the device up in the background while it parses the GTF and opens the reads: without a device it must
+    end with a message and exit code 1 - not decode into buffers it never got."""
+    import os
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "tests", "golden", "kat", "E10_rescue")
+    exe = os.path.join(root, "mmannot_amd", "mmannot-amd")
+    for reads in ([os.path.join(d, "r.bam")], [os.path.join(d, "r.bam")] * 2):
+        p = subprocess.run([exe, "-a", os.path.join(d, "a.gtf"), "-c", os.path.join(d, "c.cfg"), "-o", os.devnull, "-r"] + reads,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert p.returncode == 1
+        assert "HIP device" in p.stderr.decode() or "hip" in p.stderr.decode().lower(), p.stderr.decode()[-300:]
