@@ -526,6 +526,9 @@ int main(int argc, char **argv) {
     std::vector<uint64_t> masks;
     std::vector<double> sums;
     if (host_book) {
+      // (tests: a marker line between the reads printed in file order and the ones still pending here, which the reference prints in
+      // its hash map's iteration order - only the first part has an order to compare)
+      if (read_stats && getenv("MM_CLI_MARK_FLUSH")) read_stats_out << "#pending at end of file\n";
       for (auto &e : pending) {                          // EOF flush :1783-1800
         if (!e.second.regions.empty()) {
           print_read_stats(e.first, e.second.raw, e.second.regions);
