@@ -834,7 +834,9 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   }
   __syncthreads();
   if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
-  if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
+  // (the host has zeroed hist: a tile's names fall into a few of the 512 buckets in most inputs, and each count is a store of its own
+  // into another row - writing all 512 was 6 % of the kernel)
+  if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) if (sHist[d]) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
   if (grouped_strategy && haveKey && threadIdx.x == 0) {
     if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
     if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
@@ -1136,7 +1138,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
     u32 loff = x - tot;
     for (u32 q = 0; q < w; ++q) loff += wsum[q];
     if (t == RS_BINS - 1) tcountS = loff + tot;                  // number of pairs this tile holds
-    goff[t] = base[t] + (t < (1u << L.width) ? hist[(size_t) t * nblk + blockIdx.x] : 0u) - loff;
+    // (a digit this tile does not hold needs no offset: its row is another 4-byte gather)
+    goff[t] = base[t] + ((tot && t < (1u << L.width)) ? hist[(size_t) t * nblk + blockIdx.x] : 0u) - loff;
     u32 run = loff;
     for (u32 q = 0; q < RS_NW; ++q) { const u32 c = cntw[q][t]; cntw[q][t] = (unsigned short) run; run += c; }
   }
@@ -2595,6 +2598,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   const int n_passes = dflt ? leaf_layout(span_bits).passes : 2;
   const bool force_leaf = dflt && need_groups && n_passes == 1;
   const bool fuse_hist = force_leaf && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
+  if (fuse_hist) HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t) RS_BINS * nblk * sizeof(u32), c->stream));   // k_probe stores the non-zero counts only
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
   PhaseTimer t(c, MM_PHASE_PROBE);
