@@ -547,3 +547,56 @@ def test_twelve_byte_link_format(gpu_lib, oracle, strategy):
             assert table.dump(["t"]) == oracle.format_table(desc, ref.row_mask, ref.row_count, "t"), (resident, batches)
             ctr.close()
     index.close()
+
+
+@pytest.mark.parametrize("shift", [7, 10])
+@pytest.mark.parametrize("l", [-1.0, 0.5, 25.0])
+def test_reads_across_bin_boundaries(gpu_lib, oracle, shift, l):
+    """The slot of a bin also lists the intervals that start in the first min(W, 256) bases of the next bin, so that a read ending
+    there needs one slot: reads ending one base before, at and after that reach, intervals starting at each of those offsets, a bin
+    with more records than a slot line holds inline, and an interval open across all of them - against the oracle, per hit."""
+    mm = gpu_lib
+    rng = np.random.default_rng(77 + shift)
+    desc = sr.random_config(rng, n_lines=4, max_per_line=3)
+    W = 1 << shift
+    reach = min(W, 256)
+    chr_, start, end, typ, strand = [], [], [], [], []
+    def iv(c, s, length, t):
+        chr_.append(c); start.append(s); end.append(s + length - 1); typ.append(t % desc.E); strand.append(1 + (t & 1))
+    t = 0
+    for c in (0, 1):
+        iv(c, 2 * W + 17, 9 * W, t); t += 1                       # open at the left edge of every bin below
+        for k in range(3, 9):
+            B = k * W
+            for off in (-1, 0, 1, reach - 2, reach - 1, reach, reach + 1, W - 1):
+                iv(c, B + off, 30 + 7 * (t % 5), t); t += 1
+            if k == 5:
+                for j in range(9):                                # more than the seven inline records, inside the reach of bin 4
+                    iv(c, B + 5 + j // 3, 40, t); t += 1
+    order = np.lexsort((np.arange(len(start)), np.array(start), np.array(chr_)))
+    ix = dict(chr=np.array(chr_, dtype=np.int32)[order], start=np.array(start, dtype=np.int64)[order], end=np.array(end, dtype=np.int64)[order],
+              type=np.array(typ, dtype=np.int32)[order], strand=np.array(strand, dtype=np.uint8)[order], n_chromosomes=2)
+    tid, rs, re_, rstr, nh, qid = [], [], [], [], [], []
+    q = 0
+    for c in (0, 1):
+        for k in range(3, 9):
+            B = k * W
+            for back in range(1, min(W, 120), 7):
+                for L in (20, 60, 100, reach - 1, reach, reach + 1, 2 * reach, W + reach, 3 * W):
+                    s = B - back
+                    for rep in range(2 if (back + L) % 5 == 0 else 1):           # a few two-hit names
+                        tid.append(c); rs.append(s); re_.append(s + L - 1 + rep); rstr.append((back + L + rep) & 1)
+                        nh.append(2 if (back + L) % 5 == 0 else 1); qid.append(q)
+                    q += 1
+    reads = dict(tid=np.array(tid, dtype=np.int32), start=np.array(rs, dtype=np.int64), end=np.array(re_, dtype=np.int64),
+                 strand=np.array(rstr, dtype=np.uint8), nh=np.array(nh, dtype=np.uint32), qid=np.array(qid, dtype=np.uint32))
+    cfg = to_cfg(mm, desc)
+    for s_ in ("U", "F"):
+        for y in ("default", "ratio"):
+            ref = oracle.run(desc, ix, reads, overlap=l, strandedness=s_, strategy=y, want_hit_mask=True)
+            r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s_, strategy=y, batches=2, bin_shift=shift)
+            assert (r["hit"] == ref.hit_mask).all(), f"hit masks differ ({s_}, {y})"
+            assert r["stats"] == ref.stats
+            assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+            r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s_, strategy=y, batches=1, bin_shift=shift, keep=False)
+            assert r["stats"] == ref.stats and r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
