@@ -75,6 +75,8 @@ extern "C" int mm_device_count(void) {
 
 // ----------------------------------------------------------------------------- device structures
 #define GT_CAP (1u << 16)          // global element-set table (distinct rows of the count table)
+#define GT_NEAR_END 512u           // = RS_BINS: slots below it are handed out first (see gt_find_or_insert)
+#define GT_NEAR_PROBES 16u
 #define LT_CAP 512u                // per-workgroup LDS table (with 1024 entries the merge kernel could not hold 8 waves per SIMD)
 #define LT_MAXPROBE 8u             // a set that does not find a slot this fast goes to the global table instead
 #define NO_KEY 0xFFFFFFFFu
@@ -97,7 +99,8 @@ enum { INFO_M = 0,      // number of records in the grouping pipeline
        INFO_BIGNH = 3,  // some multi-hit record has NH >= 65535: payloads carry the record index instead of (slot, NH)
        INFO_UNSORTED = 4,  // the multi-hit records' qids are not already non-decreasing in file order (name-grouped input is)
        INFO_NLIST = 5,  // number of non-empty buckets listed by k_bucket_bounds (leaf layout with more than one partition pass)
-       INFO_WORDS = 6 };
+       INFO_WIDEKEY = 6,  // -y ratio: some sort key (table slot) of the batch is not below RS_BINS: two sort passes instead of one
+       INFO_WORDS = 7 };
 
 __host__ __device__ inline int bits_for_range(unsigned int span) {  // bits needed for keys in [0, span]
   int b = 1;
@@ -130,9 +133,12 @@ __device__ __forceinline__ SortLayout batch_layout(const unsigned int *info, int
     return leaf_layout(qmax >= qmin ? bits_for_range(qmax - qmin) : 1);
   }
   SortLayout L;
+  L.shift0 = 0; L.leaf = false;
+  // -y ratio sorts by table slot.  New element sets are placed in the table's first RS_BINS slots while there is room
+  // (gt_find_or_insert), and few runs ever see more sets than that: one pass of one RS_BINS-wide digit then sorts the batch
+  if (fixed_bits == 16 && !info[INFO_WIDEKEY]) { L.passes = 1; L.width = LEAF_DIGIT_BITS; return L; }
   L.passes = (fixed_bits + 7) / 8;
   L.width = (u32) ((fixed_bits + L.passes - 1) / L.passes);
-  L.shift0 = 0; L.leaf = false;
   return L;
 }
 // passes this batch really runs: one (the compacting first pass) when the records are already grouped by name
@@ -150,6 +156,9 @@ struct GlobalTable {
   u64 *cnt;      // integer count (default / unique)
   double *sum;   // -y ratio accumulator (file-order double adds, mmannot.cpp:1730)
   u32 *err;      // ERR_* of the first problem a kernel met (0 = none); read by mm_sync
+  u32 nearProbes;  // -y ratio: GT_NEAR_PROBES slots of the table's first RS_BINS are tried first (gt_find_or_insert); else 0 - counts
+                   // that are added to with atomics are better off spread over the whole table (hot rows side by side in one cache
+                   // line cost k_leaf a quarter of its time)
 };
 enum { ERR_TABLE_FULL = 1, ERR_QID_BOUND = 2, ERR_SINGLE_HIT = 3, ERR_NH_LIST = 4, ERR_QID_LO = 5 };
 
@@ -266,9 +275,25 @@ __device__ __forceinline__ u32 slot_of_set(LdsTable &t, const struct GlobalTable
 
 // returns slot or NO_KEY when full (error flag raised); slots [GT_FIRST_SLOT, GT_NO_SLOT) only (see the payload encoding)
 __device__ __forceinline__ u32 gt_find_or_insert(const GlobalTable &g, u64 m) {
-  u32 h = hash64(m) & (GT_CAP - 1);
+  // near region first (-y ratio): a set's probe sequence starts with GT_NEAR_PROBES slots of [GT_FIRST_SLOT, GT_NEAR_END) and goes on in the rest
+  // of the table.  Slots are never emptied, so a lookup walks the same sequence as the insertion did.  While a run knows fewer than a
+  // few hundred sets - nearly every run - all its slots are below RS_BINS, which is what lets -y ratio sort its batches in one pass.
+  const u32 hh = hash64(m);
+  u32 h = GT_FIRST_SLOT + hh % (GT_NEAR_END - GT_FIRST_SLOT);
+#pragma unroll 1
+  for (u32 p = 0; p < g.nearProbes; ++p) {
+    u64 k = *(volatile u64 *) &g.key[h];
+    if (k == 0) {
+      k = atomicCAS(&g.key[h], 0ull, m);
+      if (k == 0) k = m;
+    }
+    if (k == m) return h;
+    if (++h == GT_NEAR_END) h = GT_FIRST_SLOT;
+  }
+  h = hh & (GT_CAP - 1);
+#pragma unroll 1
   for (u32 p = 0; p < GT_CAP; ++p) {
-    if (h < GT_FIRST_SLOT || h == GT_NO_SLOT) { h = GT_FIRST_SLOT; continue; }
+    if (h < (g.nearProbes ? GT_NEAR_END : GT_FIRST_SLOT) || h == GT_NO_SLOT) { h = g.nearProbes ? GT_NEAR_END : GT_FIRST_SLOT; continue; }
     u64 k = *(volatile u64 *) &g.key[h];
     if (k == 0) {
       k = atomicCAS(&g.key[h], 0ull, m);
@@ -712,7 +737,7 @@ __global__ __launch_bounds__(256) void k_expand12(const u32 *__restrict__ pk, in
 // what a k_probe instance takes for granted (the general one reads everything from its arguments)
 enum { PV_GENERAL = 0, PV_COUNT = 1,        // per-hit counting only: default with the single-hit promise, unique
        PV_GROUPS_HIST = 2, PV_GROUPS = 3,   // default with multi-hit records, with / without the fused bucket histogram
-       PV_RATIO = 4 };
+       PV_RATIO = 4, PV_RATIO_HIST = 5 };   // -y ratio, without / with the fused histogram of the one-pass sort by table slot
 template <int OVL, int VAR>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
                                                int single, u32 qlo, size_t n, u64 *__restrict__ hm, u32 *__restrict__ gkey, u32 *__restrict__ gpay,
@@ -733,7 +758,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   // (VAR == PV_GENERAL) costs a pair of scalar registers held across the loop, and the kernel already keeps some in VGPR lanes
   constexpr bool V = VAR != PV_GENERAL;
   const uint2 *chrSlot = (V || P.nchr <= (u32) MM_LDS_CHR) ? sChr : P.chrSlot;
-  const bool useHist = V ? (VAR == PV_GROUPS_HIST) : (hist != nullptr);
+  const bool useHist = V ? (VAR == PV_GROUPS_HIST || VAR == PV_RATIO_HIST) : (hist != nullptr);
   const bool haveKey = V ? (VAR != PV_COUNT) : (gkey != nullptr);
   const bool keepSets = V ? false : (hm != nullptr && P.keep);
   const bool useSlots = V ? true : (P.useSlots != 0);
@@ -750,7 +775,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   u32 cHU = 0, cAM = 0, cRN = 0;   // hits | unassigned << 16;  ambiguous | multiple << 16;  reads | unique << 16
   u32 walked = 0;
   const bool grouped_strategy = V ? (VAR == PV_GROUPS || VAR == PV_GROUPS_HIST) : (P.strategy == MM_STRAT_DEFAULT);
-  const bool ratio = V ? (VAR == PV_RATIO) : (P.strategy == MM_STRAT_RATIO);
+  const bool ratio = V ? (VAR == PV_RATIO || VAR == PV_RATIO_HIST) : (P.strategy == MM_STRAT_RATIO);
   const bool uniqueOnly = (V && VAR != PV_COUNT) ? false : (P.strategy == MM_STRAT_UNIQUE);
   const bool randomStrategy = V ? false : (P.strategy == MM_STRAT_RANDOM);
   const size_t first = useHist ? (size_t) blockIdx.x * RS_TILE : (size_t) blockIdx.x * blockDim.x;
@@ -775,7 +800,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
     cHU += (processed ? 1u : 0u) | ((processed && np == 0) ? 0x10000u : 0u);
     cAM += ((processed && np > 1) ? 1u : 0u) | (grouped ? 0x10000u : 0u);
-    if (useHist) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
+    if (useHist && !ratio) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
       const u64 gm = __ballot(grouped);
       if (gm) {
         const u32 d = min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u);   // (an id outside the promised range is an error anyway)
@@ -799,7 +824,10 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
     //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
     if (counted && !ratio) count_set(T, G, mask);
-    if (ratio && counted) key = slot_of_set(T, G, mask);
+    if (ratio && counted) { key = slot_of_set(T, G, mask); if (key != NO_KEY && key >= RS_BINS) bigNh = 1; }   // (-y ratio: the flag means "wide key")
+    // -y ratio: the one-pass sort's digit is the slot itself (a handful of rows take most hits: equal digits are counted together);
+    // should a slot of the batch turn out not to be below RS_BINS, this histogram is void and k_rs_hist counts 8-bit digits instead
+    if (useHist && ratio) wave_hist_add<0>(sHist, key & (RS_BINS - 1u), key != NO_KEY, true);
     else if (grouped && mask != 0) {
       if ((mask & (mask - 1)) == 0) pay = (u32) (__ffsll((long long) mask) - 1);   // one element: the payload names it
       else pay = slot_of_set(T, G, mask) & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
@@ -816,6 +844,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); bigNh |= __shfl_down(bigNh, off); }
     if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (bigNh) atomicOr(&sq[2], 1u); }
   }
+  if (ratio && haveKey && __ballot(bigNh != 0) && lane == 0) atomicOr(&sq[2], 1u);
   {
     u32 c[6] = {cHU & 0xFFFFu, cHU >> 16, cAM & 0xFFFFu, cAM >> 16, cRN & 0xFFFFu, cRN >> 16};
 #pragma unroll
@@ -842,6 +871,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
     if (sq[2]) atomicOr(&info[INFO_BIGNH], 1u);
   }
+  if (ratio && haveKey && threadIdx.x == 0 && sq[2]) atomicOr(&info[INFO_WIDEKEY], 1u);
   lds_table_flush(T, G);
 }
 
@@ -899,8 +929,9 @@ __device__ __forceinline__ bool rs_load(const u32 *__restrict__ kin, const u32 *
 // and the batch takes the general path.
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 *__restrict__ info,
-                                                        size_t n, int rebase, int shift, int fixed_bits, u32 *__restrict__ hist, u32 nblk) {
+                                                        size_t n, int rebase, int shift, int fixed_bits, u32 *__restrict__ hist, u32 nblk, int only_if_wide) {
   __shared__ u32 h[RS_BINS];
+  if (FIRST && only_if_wide && !info[INFO_WIDEKEY]) return;      // k_probe's own count of the slots stands (-y ratio, one pass)
   __shared__ u32 segF[RS_ROUNDS * RS_NW], segL[RS_ROUNDS * RS_NW];
   __shared__ u32 tileCnt, tileBad;
   if (!FIRST && (shift >> 3) >= batch_passes(info, fixed_bits)) return;   // this pass is not needed for this batch's key range
@@ -1075,7 +1106,8 @@ __global__ __launch_bounds__(256) void k_rs_scan(u32 *__restrict__ hist, u32 nbl
 template <bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
                                                            u32 *__restrict__ vout, const u32 *__restrict__ info, size_t n, int rebase, int shift,
-                                                           int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk, int forced_leaf) {
+                                                           int fixed_bits, const u32 *__restrict__ hist, const u32 *__restrict__ base, u32 nblk, int forced_leaf,
+                                                           u32 *__restrict__ kfin, u32 *__restrict__ vfin) {
   __shared__ u32 lkey[RS_TILE];
   __shared__ u32 lval[RS_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short cntw[RS_NW][RS_BINS];   // A: digit counts per wave; C: running tile-local offset per wave (< 8192)
@@ -1087,6 +1119,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u32 *__restrict
   // the host took the one-pass leaf layout for granted (k_probe counted buckets) but a read-name id lies outside the range it was
   // promised: the histogram does not fit this layout - write nothing; k_leaf reports the batch
   if (forced_leaf && L.passes != 1) return;
+  // -y ratio, one pass (batch_layout): this pass's output is the sorted batch - it goes where the second pass would have left it
+  if (FIRST && fixed_bits == 16 && L.passes == 1) { kout = kfin; vout = vfin; }
   const size_t lo = (size_t) blockIdx.x * RS_TILE;
   const size_t lim = FIRST ? n : (size_t) info[INFO_M];
   if (lo >= lim) return;
@@ -1714,23 +1748,25 @@ __global__ __launch_bounds__(RATIO_THREADS) void k_ratio_rows(const u32 *__restr
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   int kLut = 0x7fffffff;
   // this workgroup's slots: one coalesced read of their segment bounds instead of a dependent load per slot
-  const u32 slot0 = blockIdx.x * RATIO_SLOTS_PER_WG;
+  // (interleaved: workgroup b takes the slots b, b + gridDim.x, ... - the table hands out its first few hundred slots first, and the
+  // hot rows of a run sit among them: a workgroup per row, not 128 of them in a row)
+#define RATIO_SLOT(I) (blockIdx.x + (u32) (I) * gridDim.x)
   if (t < RATIO_SLOTS_PER_WG) {
-    u32 lo = segLo[slot0 + t], hi = segHi[slot0 + t];
+    u32 lo = segLo[RATIO_SLOT(t)], hi = segHi[RATIO_SLOT(t)];
     // Short rows first, each by ONE lane, all of them at once: most rows of a table are element sets that collect a handful of hits
     // per batch (ambiguous combinations), and the file-order sum of a few terms is just that - a loop of IEEE adds
     // (mmannot.cpp:1730).  The workgroup-wide machinery below is for the rows that collect thousands.
-    if (hi > lo && hi - lo <= RATIO_SHORT_ROW && row_in_chunk(G.key[slot0 + t], chunk, nchunks)) {
-      double S = G.sum[slot0 + t];
+    if (hi > lo && hi - lo <= RATIO_SHORT_ROW && row_in_chunk(G.key[RATIO_SLOT(t)], chunk, nchunks)) {
+      double S = G.sum[RATIO_SLOT(t)];
       for (u32 j = lo; j < hi; ++j) S = __dadd_rn(S, __ddiv_rn(1.0, (double) svals[j]));
-      G.sum[slot0 + t] = S;
+      G.sum[RATIO_SLOT(t)] = S;
       hi = lo;                                               // done
     }
     sLo[t] = lo; sHi[t] = hi;
   }
   __syncthreads();
   for (u32 si = 0; si < RATIO_SLOTS_PER_WG; ++si) {
-    const u32 slot = slot0 + si;
+    const u32 slot = RATIO_SLOT(si);
     const u32 lo = sLo[si], hi = sHi[si];
     if (hi <= lo) continue;                                  // block-uniform
     if (!row_in_chunk(G.key[slot], chunk, nchunks)) continue;  // (block-uniform) another chunk's row
@@ -2327,6 +2363,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
   HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
+  c->G.nearProbes = c->opt.strategy == MM_STRAT_RATIO ? GT_NEAR_PROBES : 0u;
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
   HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 2) * 4));   // + the scan's "workgroups done" counter
   HIPCHK(hipMemset(c->d_rowTot, 0, (RS_ROW_COUNT + 2) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
@@ -2452,21 +2489,23 @@ static int sort_pairs(mm_ctx *c, size_t n, int passes, int fixed_bits, int rebas
   const u32 nblk = (u32) ((n + RS_TILE - 1) / RS_TILE);
   // first pass: straight from k_probe's (gkey, gpay), filtering and compacting on the fly -> (kB, vB)
   // (have_hist: k_probe has counted the tiles' buckets itself - one-pass leaf layout taken for granted, no order check, no count row)
-  if (!have_hist)
-    hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk);
+  // (-y ratio with k_probe's histogram: valid for the one-pass layout only - the kernel returns at once unless the batch has a wide key)
+  if (!have_hist || fixed_bits)
+    hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_M, n, rebase, 0, fixed_bits, c->d_hist, nblk,
+                       have_hist ? 1 : 0);
   const u32 nrows = (rebase && !have_hist) ? RS_ROW_COUNT + 1 : RS_BINS;      // (with the order check the scan also covers row RS_ROW_COUNT, the offsets of a plain compaction)
   hipLaunchKernelGGL(k_rs_scan, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, c->d_hist, nblk, nrows, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1,
                      c->d_M, 0, fixed_bits, rebase, c->d_walk);
   hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, c->d_gkey, c->d_gpay, c->d_kB, c->d_vB, c->d_M, n, rebase, 0,
-                     fixed_bits, c->d_hist, c->d_rowTot, nblk, have_hist ? 1 : 0);
+                     fixed_bits, c->d_hist, c->d_rowTot, nblk, (have_hist && !fixed_bits) ? 1 : 0, c->d_kA, c->d_vA);
   u32 *kin = c->d_kB, *vin = c->d_vB, *kout = c->d_kA, *vout = c->d_vA;
   for (int pass = 1; pass < passes; ++pass) {
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, rebase, shift, fixed_bits, c->d_hist, nblk);
+    hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, c->d_M, n, rebase, shift, fixed_bits, c->d_hist, nblk, 0);
     hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS / 4), dim3(256), 0, c->stream, c->d_hist, nblk, (u32) RS_BINS, c->d_rowTot, c->d_rowTot + RS_ROW_COUNT + 1, c->d_M, shift,
                        fixed_bits, 0, c->d_walk);
     hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nblk), dim3(RS_THREADS), 0, c->stream, kin, vin, kout, vout, c->d_M, n, rebase, shift, fixed_bits,
-                       c->d_hist, c->d_rowTot, nblk, 0);
+                       c->d_hist, c->d_rowTot, nblk, 0, nullptr, nullptr);
     std::swap(kin, kout); std::swap(vin, vout);
   }
   HIPCHK(hipGetLastError());
@@ -2597,7 +2636,8 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   const int span_bits = dflt ? bits_for((qid_bound ? qid_bound : 1) - qid_lo) : 16;
   const int n_passes = dflt ? leaf_layout(span_bits).passes : 2;
   const bool force_leaf = dflt && need_groups && n_passes == 1;
-  const bool fuse_hist = force_leaf && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
+  // k_probe also counts the first sort pass's digits per tile: buckets of the leaf layout, or (-y ratio) the table slots of a one-pass sort
+  const bool fuse_hist = (force_leaf || ratio) && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
   if (fuse_hist) HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t) RS_BINS * nblk * sizeof(u32), c->stream));   // k_probe stores the non-zero counts only
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
@@ -2606,7 +2646,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   // more chromosomes than the LDS table holds; MMANNOT_AMD_GENERAL_PROBE=1 forces it for A/B measurements and tests)
   int var = PV_GENERAL;
   if (P.useSlots && P.nchr <= (u32) MM_LDS_CHR && !P.keep && P.strategy != MM_STRAT_RANDOM && !getenv("MMANNOT_AMD_GENERAL_PROBE"))
-    var = ratio ? PV_RATIO : ((dflt && need_groups) ? (fuse_hist ? PV_GROUPS_HIST : PV_GROUPS) : PV_COUNT);
+    var = ratio ? (fuse_hist ? PV_RATIO_HIST : PV_RATIO) : ((dflt && need_groups) ? (fuse_hist ? PV_GROUPS_HIST : PV_GROUPS) : PV_COUNT);
 #define MM_LAUNCH_PROBE(OVL, VAR)                                                                                                  \
   hipLaunchKernelGGL((k_probe<OVL, VAR>), dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big,    \
                      single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk,                   \
@@ -2617,6 +2657,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
     case PV_GROUPS_HIST: MM_LAUNCH_PROBE(OVL, PV_GROUPS_HIST); break;   \
     case PV_GROUPS: MM_LAUNCH_PROBE(OVL, PV_GROUPS); break;             \
     case PV_RATIO: MM_LAUNCH_PROBE(OVL, PV_RATIO); break;               \
+    case PV_RATIO_HIST: MM_LAUNCH_PROBE(OVL, PV_RATIO_HIST); break;     \
     default: MM_LAUNCH_PROBE(OVL, PV_GENERAL);                          \
   }
   switch (c->opt.overlap_mode) {

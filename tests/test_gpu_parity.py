@@ -390,7 +390,9 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
     """A multi-hit record's element set travels to the merge kernel as its 16-bit table slot and 0xFFFF there means "no
     element".  Sets whose home slot is 65535 ({0,10,13,16,17,18,20}, {20,39,49}) or that linear probing pushes there (two
     sets with home 65534) must still reach their group's union (mmannot.cpp:1678-1690): one Order line of 21 tied elements,
-    -l -1, NH = 2 reads inside intervals of exactly those elements."""
+    -l -1, NH = 2 reads inside intervals of exactly those elements.  New sets take the table's first 512 slots while there is
+    room, so 2000 other sets come first (single-hit reads, in batches of their own) - the sets of interest then go to their home
+    slots in the rest of the table.  The same input under -y ratio sorts by slots on both sides of 512: two sort passes."""
     import synth_ref  # noqa: F401  (path set-up)
     from oracle import mm_oracle as mo
     mm = gpu_lib
@@ -404,8 +406,15 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
     before_last = [int(m) for m in allm[home == 65534] if bin(int(m)).count("1") >= 2][:3]   # the 2nd and 3rd probe on to 65535
     assert target in at_last and len(before_last) == 3
     sets = at_last + before_last + [0b11, 1 << 5]
+    rng = np.random.default_rng(65535)
+    fillers = []
+    while len(fillers) < 2000:
+        m = int(rng.integers(3, 1 << E))
+        if bin(m).count("1") >= 2 and m not in sets and m not in fillers:
+            fillers.append(m)
+    regions = sets + fillers
     chr_, start, end, typ = [], [], [], []
-    for j, m in enumerate(sets):
+    for j, m in enumerate(regions):
         base = 10000 * (j + 1)
         for e in range(E):
             if m >> e & 1:
@@ -413,17 +422,21 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
     order = np.lexsort((np.arange(len(start)), start))
     ix = dict(chr=np.array(chr_, dtype=np.int32)[order], start=np.array(start, dtype=np.int64)[order], end=np.array(end, dtype=np.int64)[order],
               type=np.array(typ, dtype=np.int32)[order], strand=np.ones(len(start), dtype=np.uint8), n_chromosomes=1)
-    # reads: name q has NH = 2; its two hits sit in regions a(q), b(q) (often the same region, sometimes one in empty space)
-    rng = np.random.default_rng(65535)
+    # filler reads first: 3600 single-hit reads, one region after the other (every filler set is known after the first 2000)
     tid, st, en, nh, qid = [], [], [], [], []
+    for q in range(3600):
+        base = 10000 * (len(sets) + q % len(fillers) + 1)
+        tid.append(0); st.append(base + 300); en.append(base + 349); nh.append(1); qid.append(q)
+    n_fill = len(st)
+    # then the reads of interest: name q has NH = 2; its two hits sit in regions a(q), b(q) (often the same region, sometimes one in empty space)
     for q in range(600):
         a = int(rng.integers(0, len(sets)))
         b = a if rng.random() < 0.5 else int(rng.integers(0, len(sets) + 1))
         for r in (a, b):
             base = 10000 * (r + 1) if r < len(sets) else 5000        # 5000: no interval there
             s = base + 200 + int(rng.integers(0, 50))
-            tid.append(0); st.append(s); en.append(s + 49); nh.append(2); qid.append(q)
-    perm = rng.permutation(len(st))
+            tid.append(0); st.append(s); en.append(s + 49); nh.append(2); qid.append(3600 + q)
+    perm = np.concatenate([np.arange(n_fill), n_fill + rng.permutation(len(st) - n_fill)])
     reads = dict(tid=np.array(tid, dtype=np.int32)[perm], start=np.array(st, dtype=np.int64)[perm], end=np.array(en, dtype=np.int64)[perm],
                  strand=np.ones(len(st), dtype=np.uint8), nh=np.array(nh, dtype=np.uint32)[perm], qid=np.array(qid, dtype=np.int64)[perm])
     cfg = to_cfg(mm, desc)
@@ -433,11 +446,16 @@ def test_table_slot_65535_is_never_a_payload(gpu_lib, oracle):
             reads = {k: v[o] for k, v in reads.items()}
         ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="U", strategy="default", want_hit_mask=True)
         assert target in set(ref.hit_mask.tolist()) and target in set(ref.row_mask.tolist())
-        for batches in (1, 3):
+        for batches in (2, 3, 1):       # (2 and 3: the first batch holds filler reads only)
             r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="U", strategy="default", batches=batches)
             assert (r["hit"] == ref.hit_mask).all()
             assert r["stats"] == ref.stats, (order_kind, batches)
             assert r["table"] == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset"), (order_kind, batches)
+    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="U", strategy="ratio", want_hit_mask=True)
+    for batches, keep in ((1, True), (3, False)):
+        r = run_gpu(mm, cfg, ix, reads, overlap=-1.0, strandedness="U", strategy="ratio", batches=batches, keep=keep)
+        assert r["stats"] == ref.stats
+        assert dict(zip(r["masks"].tolist(), r["sums"].view(np.uint64).tolist())) == dict(zip(ref.row_mask.tolist(), ref.row_sum.view(np.uint64).tolist()))
 
 
 @pytest.mark.parametrize("stride,shuffle", [(1, True), (700, True), (700, False), (70000, True), (400000, True)])
