@@ -274,11 +274,18 @@ const char *mm_reader_error(const mm_reader *r);
 int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n, mm_nh_big *big, size_t big_cap, size_t *n_big, uint32_t *max_nh);
 /* smallest qid among the tuples with NH > 1 of the batch mm_reader_next delivered last (mm_annotate_batch's qid_lo; the qid bound when there is none) */
 uint64_t mm_reader_qid_lo(const mm_reader *r);
+
 uint64_t mm_reader_qid_bound(const mm_reader *r);
 uint64_t mm_reader_n_reads(const mm_reader *r);       /* the "lines read" counter of Counter::read, mmannot.cpp:1782 */
 const char *mm_reader_name(const mm_reader *r, uint32_t qid);
 const char *mm_reader_take_log(mm_reader *r);         /* stderr text produced since the last call */
 void mm_reader_close(mm_reader *r);
+
+/* Raw DEFLATE (RFC 1951) of one BGZF block's payload by the reader's own block decoder -> out[0..out_len).  0 = decoded and the
+ * stream ended exactly at out_len; non-zero = this decoder does not take the stream (the reader then hands the block to zlib, as it
+ * does for every block when MM_READER_ZLIB=1).  Replaces the zlib calls behind the reference's gzread (mmannot.cpp:903-960 read its
+ * BAM through zlib); exported for the differential tests (tests/test_decoder.py). */
+int mm_inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
 
 /* ---- synthetic workload generators for bench.py / tests (device kernels, counter-based RNG;
  * tests/synth_ref.py holds the numpy twin).  See DESIGN.md "Synthetic inputs". */

@@ -107,6 +107,7 @@ SYMBOLS = {
                                  C.POINTER(C.c_uint32)]),
     "mm_reader_qid_bound": (C.c_uint64, [C.c_void_p]),
     "mm_reader_qid_lo": (C.c_uint64, [C.c_void_p]),
+    "mm_inflate_block": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "mm_reader_n_reads": (C.c_uint64, [C.c_void_p]),
     "mm_reader_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mm_reader_take_log": (C.c_char_p, [C.c_void_p]),

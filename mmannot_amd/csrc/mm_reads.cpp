@@ -27,6 +27,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -34,6 +35,7 @@
 
 #include "../../include/mmannot_amd.h"
 #include "mm_hostutil.h"
+#include "mm_inflate.h"
 
 using namespace mmh;
 
@@ -212,6 +214,7 @@ struct BgzfPipe {
   int fd = -1;
   int n_threads = 4;
   bool frame = false;
+  bool own_inflate = !(getenv("MM_READER_ZLIB") && *getenv("MM_READER_ZLIB") && *getenv("MM_READER_ZLIB") != '0');   // (A/B and tests)
   struct Batch {
     std::vector<uint8_t> data;
     size_t len = 0;           // bytes in data (prefix included)
@@ -330,9 +333,12 @@ struct BgzfPipe {
         z_stream z;
         memset(&z, 0, sizeof z);
         if (inflateInit2(&z, -15) != Z_OK) { fail[tid] = 1; return; }
+        std::unique_ptr<mminf::Tables> tables(own_inflate ? new mminf::Tables : nullptr);
         const size_t b_lo = nb * (size_t) tid / (size_t) n_threads, b_hi = nb * ((size_t) tid + 1) / (size_t) n_threads;
         for (size_t i = b_lo; i < b_hi; ++i) {
           if (ulen[i] == 0) continue;
+          // the block decoder of mm_inflate.h first; whatever it does not take (any non-zero return) goes to zlib
+          if (tables && mminf::inflate_block(raw + coff[i] + 18, clen[i] - 26, &B.data[uoff[i]], ulen[i], *tables) == 0) continue;
           if (inflateReset(&z) != Z_OK) { fail[tid] = 1; break; }
           z.next_in = const_cast<Bytef *>(raw + coff[i] + 18); z.avail_in = (uInt) (clen[i] - 26);
           z.next_out = &B.data[uoff[i]]; z.avail_out = (uInt) ulen[i];
@@ -1169,4 +1175,12 @@ extern "C" void mm_reader_close(mm_reader *r) {
             r->qids.t_a, r->qids.t_b, r->qids.t_c, r->t_emit);
   r->src.close();
   delete r;
+}
+
+// One raw DEFLATE stream (the payload of a BGZF block) -> out[0..out_len), by the reader's own block decoder (mm_inflate.h).
+// 0 = decoded, ending exactly at out_len; anything else = not taken (the reader then uses zlib).  Exported for the differential tests.
+extern "C" int mm_inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
+  if ((!in && in_len) || (!out && out_len)) return -1;
+  std::unique_ptr<mminf::Tables> t(new mminf::Tables);
+  return mminf::inflate_block(in, in_len, out, out_len, *t);
 }
