@@ -297,3 +297,26 @@ def test_reader_with_zlib_equals_reader_with_own_inflate(oracle, tmp_path, monke
     monkeypatch.setenv("MM_READER_ZLIB", "1")
     x1, y1 = api.ReadsDecoder(str(p), an).read_all()
     assert len(x0) == n and (x0 == x1).all() and (y0 == y1).all()
+
+
+def test_record_of_several_megabytes_across_a_batch_boundary(oracle, tmp_path):
+    """A 9 MB record (6 M bases) that starts 5.7 MB before the end of the BGZF pipe's first batch and a 7.5 MB one later on: the
+    unframed tail that moves to the next batch is larger than most batches' whole carry.  Same tuples as the plain-gzip reader,
+    which never frames."""
+    import mmannot_amd.api as api
+    kat = os.path.join(gu.GOLD, "kat", "X1_xa")
+    an = api.Annotation(os.path.join(kat, "c.cfg"), os.path.join(kat, "a.gtf"))
+    rng = np.random.default_rng(9)
+    chroms = [("chr1", 100000), ("chrZ", 50000)]
+
+    def recs(n, q0, seq_len=0):
+        return oracle.bam_records_fixed(rng.integers(-1, 2, n), rng.integers(0, 90000, n), rng.integers(0, 32, n).astype(np.uint16) & 16,
+                                        q0 + rng.integers(0, 9000, n), rng.integers(20, 150, n), rng.integers(0, 9, n).astype(np.uint32), seq_len=seq_len)
+    n1 = 470000                                   # 27.7 MB of 59-byte records: the big one starts 5.7 MB before the end of the first batch (512 blocks of 65280 B)
+    body = recs(n1, 0) + recs(1, 100000, seq_len=6_000_000) + recs(3000, 0) + recs(1, 200000, seq_len=5_000_000) + recs(2000, 0)
+    p0, p1 = tmp_path / "g.bam", tmp_path / "b.bam"
+    oracle.write_bam_bytes(str(p0), chroms, body, level=1)
+    oracle.write_bam_bgzf(str(p1), chroms, body, level=1)
+    x0, y0 = api.ReadsDecoder(str(p0), an).read_all()
+    x1, y1 = api.ReadsDecoder(str(p1), an).read_all()
+    assert len(x0) == n1 + 5002 and (x0 == x1).all() and (y0 == y1).all()
