@@ -472,8 +472,10 @@ __device__ __forceinline__ u32 slot_reach_count(const ProbeParams &P, u32 w1) {
 // second 32 bytes only when the header says they hold records - and nothing at all when the
 // slot is empty, which a bitmap small enough to stay in L2 (1 bit per bin) tells: the kernel's limit is the number of
 // random 64-B sector fetches it can keep in flight, and about half of the bins of a genome hold no record.  The test is
-// a dependent L2 access of its own, so the index only carries the bitmap when at least 42 % of the slots are empty
-// (measured: HS38-shaped 49 % empty -8 % probe time, Flybase6-shaped 57 % -3 %, TAIR10-shaped 35 % +3 %).
+// a dependent L2 access of its own, so the index only carries the bitmap when at least a third of the slots are empty
+// (measured, end of round 2: HS38-shaped 50 % empty: 0.281 instead of 0.405 ms per 2^24 tuples; TAIR10-shaped, where every slot line
+// is a 128-B fetch out of the Infinity Cache and the kernel runs at that fabric's rate: 34.7 % empty -11 %, 32.3 % (256-base bins)
+// -3 %, 30.1 % (512-base bins) +3 %.  Round 1's kernel, bound elsewhere, broke even at 42 %.)
 #define MM_SLOT_WALK(VISIT)                                                                      \
   for (u32 b_ = b0; b_ <= bl; ++b_) {                                                            \
     if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue; /* empty bin: no line to fetch */ \
@@ -2286,7 +2288,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     }
     u64 nonEmpty = 0;
     for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k] + nOvh[k]) ? 1 : 0;
-    if ((double) (ns - nonEmpty) < 0.42 * (double) ns) slotBits.clear();
+    if ((double) (ns - nonEmpty) < 0.33 * (double) ns) slotBits.clear();
     // (Measured and rejected, round 2: storing the non-empty bins only - slot found through a running count kept beside each bitmap
     // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
     // SLOWER (0.354 -> 0.394 ms per 2^24 tuples): the rank arithmetic sits on the dependent chain and costs the 64-VGPR budget a spill.)
