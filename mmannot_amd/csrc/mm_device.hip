@@ -2376,6 +2376,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
 
 extern "C" void mm_ctx_destroy(mm_ctx *c) {
   if (!c) return;
+  (void) hipSetDevice(c->ix->device);
   (void) hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
   free_runs(c);
@@ -2753,12 +2754,14 @@ static int check_table(mm_ctx *c) {
 
 extern "C" int mm_sync(mm_ctx *c) {
   if (!c) return fail(MM_ERR_ARG, "mm_sync: null context");
+  HIPCHK(hipSetDevice(c->ix->device));   // (one host thread may drive contexts on several devices)
   HIPCHK(hipStreamSynchronize(c->stream));
   return check_table(c);
 }
 
 extern "C" int mm_finalize(mm_ctx *c) {
   if (!c) return fail(MM_ERR_ARG, "mm_finalize: null context");
+  HIPCHK(hipSetDevice(c->ix->device));   // (one host thread may drive contexts on several devices)
   if (!c->finalized && c->opt.strategy == MM_STRAT_DEFAULT && c->qcap) {
     PhaseTimer t(c, MM_PHASE_FLUSH);
     hipLaunchKernelGGL(k_flush_pending, dim3(256 * 4), dim3(256), 0, c->stream, c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats);
@@ -2828,6 +2831,7 @@ extern "C" uint32_t mm_row_chunk(uint64_t mask, uint32_t n_chunks) { return n_ch
 
 extern "C" int mm_set_profiling(mm_ctx *c, int on) {
   if (!c) return fail(MM_ERR_ARG, "mm_set_profiling: null context");
+  HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
   c->spans.clear();
@@ -2837,6 +2841,7 @@ extern "C" int mm_set_profiling(mm_ctx *c, int on) {
 
 extern "C" int mm_get_phase_ms(mm_ctx *c, double ms[MM_N_PHASES], uint64_t launches[MM_N_PHASES]) {
   if (!c || !ms || !launches) return fail(MM_ERR_ARG, "mm_get_phase_ms: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (int p = 0; p < MM_N_PHASES; ++p) { ms[p] = 0; launches[p] = 0; }
   for (auto &s : c->spans) {
@@ -2849,6 +2854,7 @@ extern "C" int mm_get_phase_ms(mm_ctx *c, double ms[MM_N_PHASES], uint64_t launc
 
 extern "C" int mm_get_stats(mm_ctx *c, uint64_t stats[MM_N_STATS]) {
   if (!c || !stats) return fail(MM_ERR_ARG, "mm_get_stats: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));   // (one host thread may drive contexts on several devices)
   u64 h[8];
   HIPCHK(hipMemcpyAsync(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2858,6 +2864,7 @@ extern "C" int mm_get_stats(mm_ctx *c, uint64_t stats[MM_N_STATS]) {
 
 extern "C" int mm_get_rows(mm_ctx *c, uint64_t *masks, double *sums, size_t cap, size_t *n_rows) {
   if (!c || !n_rows) return fail(MM_ERR_ARG, "mm_get_rows: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));   // (one host thread may drive contexts on several devices)
   std::vector<u64> k(GT_CAP), v(GT_CAP);
   std::vector<double> s(GT_CAP);
   HIPCHK(hipMemcpyAsync(k.data(), c->G.key, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2879,6 +2886,7 @@ extern "C" int mm_get_rows(mm_ctx *c, uint64_t *masks, double *sums, size_t cap,
 
 extern "C" int mm_get_hit_masks(mm_ctx *c, uint64_t *out, size_t n) {
   if (!c || !out) return fail(MM_ERR_ARG, "mm_get_hit_masks: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
   if (!c->opt.keep_hit_masks) return fail(MM_ERR_STATE, "mm_get_hit_masks: context created without keep_hit_masks");
   if (n > c->last_n) return fail(MM_ERR_ARG, "mm_get_hit_masks: n exceeds the last batch");
   HIPCHK(hipMemcpyAsync(out, c->d_hm, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2929,6 +2937,7 @@ extern "C" int mm_get_hit_intervals(mm_ctx *c, uint32_t *counts, uint32_t *idx, 
 
 extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
   if (!c || !out) return fail(MM_ERR_ARG, "mm_get_walk_stats: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipMemcpyAsync(out, c->d_walk, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MM_OK;
