@@ -105,6 +105,12 @@ def test_oracle_synthetic(gpu_lib, oracle, seed, l, s, y):
         finally:
             del os.environ["MMANNOT_AMD_GENERAL_PROBE"]
         assert r["stats"] == ref.stats and r["table"] == want_table
+        os.environ["MMANNOT_AMD_FULL_INDEX_ONLY"] = "1"      # and every read through the full 16-byte index (the path of reads without CIGAR operations)
+        try:
+            r = run_gpu(mm, cfg, ix, reads, overlap=l, strandedness=s, strategy=y, batches=2)
+        finally:
+            del os.environ["MMANNOT_AMD_FULL_INDEX_ONLY"]
+        assert (r["hit"] == ref.hit_mask).all() and r["stats"] == ref.stats and r["table"] == want_table
 
 
 def test_name_grouped_input(gpu_lib, oracle):
