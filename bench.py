@@ -332,6 +332,9 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
                                "dominant_phase": dom}
+            if traffic and B == (1 << 24):     # (the counters were collected on 2^24-tuple launches) the same kernel in the bytes that really moved
+                out["roofline"]["traffic_achieved"] = traffic / avg_probe_s / 1e9
+                out["roofline"]["traffic_frac"] = traffic / avg_probe_s / 1e9 / 8000.0
         out["phase_ms_per_step"] = {p: phases_all[p][0] / max(1, n_phase) for p in phases_all}
         out["phase_pass"] = f"separate untimed pass of {n_phase} resident steps with events around every phase"
         if want_cpu:
