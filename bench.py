@@ -95,6 +95,7 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa = bind_to_gpu_numa_node(local_rank) if world > 1 else None
     # MM_BENCH_FORCE_DIST=1: the multi-rank code path (process group, warm-up, merge collectives, chain) with whatever world size the
     # launcher gave, also 1 - so that the RCCL backend can be exercised on a one-GPU box
     multi = world > 1 or bool(os.environ.get("MM_BENCH_FORCE_DIST"))
@@ -345,10 +346,37 @@ def main():
                 out["cpu_baseline"] = ref
             else:
                 out["cpu_baseline"] = port
+        if numa is not None:
+            out["config"]["numa_node"] = numa
         print(json.dumps(out))
     ctr.close(); index.close()
     if multi:
         dist.destroy_process_group()
+
+
+def bind_to_gpu_numa_node(device_index: int):
+    """Several ranks per host: every rank streams its batches from pinned host memory at the link's rate, and pinned pages are
+    allocated on the NUMA node of the thread that asks for them - so the process is bound to the CPUs of its GPU's node before it
+    allocates anything (8 x 55 GB/s out of one socket's memory, half of it across the socket link, is what an unbound node can end up
+    with).  Best effort: returns the node, or None when the topology is not readable or the CPUs are not this process's to use."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
 
 
 def host_cores() -> int:
