@@ -215,6 +215,7 @@ struct BgzfPipe {
   int n_threads = 4;
   bool frame = false;
   bool own_inflate = !(getenv("MM_READER_ZLIB") && *getenv("MM_READER_ZLIB") && *getenv("MM_READER_ZLIB") != '0');   // (A/B and tests)
+  bool check_crc = !(getenv("MM_READER_NOCRC") && *getenv("MM_READER_NOCRC") && *getenv("MM_READER_NOCRC") != '0');    // (A/B: what the CRC-32 of every block costs)
   struct Batch {
     std::vector<uint8_t> data;
     size_t len = 0;           // bytes in data (prefix included)
@@ -239,14 +240,22 @@ struct BgzfPipe {
   double t_read = 0, t_inflate = 0, t_frame = 0, t_parse = 0, t_wait_prod = 0, t_wait_cons = 0;   // MM_READER_TIMING=1: printed at close
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+  // does the file start with a BGZF block: a gzip member whose extra field holds the 'BC' subfield (anywhere in it)
   static bool is_bgzf(const char *path) {
     FILE *g = fopen(path, "rb");
     if (!g) return false;
-    unsigned char h[18];
-    const bool ok = fread(h, 1, 18, g) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 &&
-                    h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    unsigned char h[12 + 256];
+    const size_t got = fread(h, 1, sizeof h, g);
     fclose(g);
-    return ok;
+    if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;
+    const size_t xlen = (size_t) (h[10] | (h[11] << 8));
+    if (12 + xlen > got) return false;
+    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+      const size_t sl = (size_t) (h[x + 2] | (h[x + 3] << 8));
+      if (h[x] == 'B' && h[x + 1] == 'C' && sl == 2 && x + 6 <= 12 + xlen) return true;
+      x += 4 + sl;
+    }
+    return false;
   }
   bool open(const char *path, bool frame_records) {
     fd = ::open(path, O_RDONLY);
@@ -309,13 +318,23 @@ struct BgzfPipe {
       while (coff.size() < BATCH_BLOCKS) {
         if (fpos == fsize) { eof = true; break; }
         const uint8_t *h = map + fpos;
-        if (fsize - fpos < 18 || h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C') { B.bad = true; eof = true; break; }
-        const size_t bsize = (size_t) (h[16] | (h[17] << 8)) + 1;       // whole block
-        if (bsize < 26 || fsize - fpos < bsize) { B.bad = true; eof = true; break; }
+        // gzip member header with FEXTRA (RFC 1952); the BGZF 'BC' subfield (SAM specification 4.1) is looked for in every block's
+        // extra field - other subfields may stand beside it - and gives the size of the whole block
+        if (fsize - fpos < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { B.bad = true; eof = true; break; }
+        const size_t xlen = (size_t) (h[10] | (h[11] << 8));
+        if (fsize - fpos < 12 + xlen + 8) { B.bad = true; eof = true; break; }
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + xlen;) {
+          const size_t sl = (size_t) (h[x + 2] | (h[x + 3] << 8));
+          if (h[x] == 'B' && h[x + 1] == 'C' && sl == 2 && x + 6 <= 12 + xlen) { bsize = (size_t) (h[x + 4] | (h[x + 5] << 8)) + 1; break; }
+          x += 4 + sl;
+        }
+        const size_t hdr = 12 + xlen;                                   // compressed data starts here (no FNAME / FCOMMENT / FHCRC in BGZF)
+        if ((h[3] & ~4) || bsize < hdr + 8 || fsize - fpos < bsize) { B.bad = true; eof = true; break; }
         uint32_t isize;
         memcpy(&isize, h + bsize - 4, 4);
         if (isize > 65536) { B.bad = true; eof = true; break; }
-        coff.push_back(fpos); clen.push_back(bsize); uoff.push_back(total); ulen.push_back(isize);
+        coff.push_back(fpos + hdr); clen.push_back(bsize - hdr - 8); uoff.push_back(total); ulen.push_back(isize);
         total += isize;
         fpos += bsize;
       }
@@ -338,12 +357,19 @@ struct BgzfPipe {
         for (size_t i = b_lo; i < b_hi; ++i) {
           if (ulen[i] == 0) continue;
           // the block decoder of mm_inflate.h first; whatever it does not take (any non-zero return) goes to zlib
-          if (tables && mminf::inflate_block(raw + coff[i] + 18, clen[i] - 26, &B.data[uoff[i]], ulen[i], *tables) == 0) continue;
-          if (inflateReset(&z) != Z_OK) { fail[tid] = 1; break; }
-          z.next_in = const_cast<Bytef *>(raw + coff[i] + 18); z.avail_in = (uInt) (clen[i] - 26);
-          z.next_out = &B.data[uoff[i]]; z.avail_out = (uInt) ulen[i];
-          const int rc = inflate(&z, Z_FINISH);
-          if (rc != Z_STREAM_END || z.avail_out != 0) { fail[tid] = 1; break; }
+          if (!(tables && mminf::inflate_block(raw + coff[i], clen[i], &B.data[uoff[i]], ulen[i], *tables) == 0)) {
+            if (inflateReset(&z) != Z_OK) { fail[tid] = 1; break; }
+            z.next_in = const_cast<Bytef *>(raw + coff[i]); z.avail_in = (uInt) clen[i];
+            z.next_out = &B.data[uoff[i]]; z.avail_out = (uInt) ulen[i];
+            const int rc = inflate(&z, Z_FINISH);
+            if (rc != Z_STREAM_END || z.avail_out != 0) { fail[tid] = 1; break; }
+          }
+          // the member's CRC-32 (its trailer: CRC32, ISIZE): a damaged block that still inflates to ISIZE bytes must not turn into tuples
+          if (check_crc) {
+            uint32_t want;
+            memcpy(&want, raw + coff[i] + clen[i], 4);
+            if ((uint32_t) crc32(0L, &B.data[uoff[i]], (uInt) ulen[i]) != want) { fail[tid] = 1; break; }
+          }
         }
         inflateEnd(&z);
       };
@@ -490,7 +516,7 @@ struct ByteSource {  // sequential reader: BGZF through BgzfPipe, anything else 
     if (eof) return false;
     if (pipe_done) { eof = true; len = pos = 0; return false; }
     cur = pipe->next(cur != nullptr);
-    if (cur->bad) { err = "corrupt BGZF block"; eof = true; len = pos = 0; return false; }
+    if (cur->bad) { err = "corrupt BGZF block (bad header, DEFLATE stream or CRC-32)"; eof = true; len = pos = 0; return false; }
     if (cur->last) pipe_done = true;
     p = cur->data.data(); len = cur->len; pos = 0;
     return true;
@@ -964,6 +990,7 @@ extern "C" int mm_reader_open(mm_reader **out, const char *path, int format, con
     char magic[5] = {0, 0, 0, 0, 0};
     r->src.read(magic, 4);
     if (strcmp(magic, "BAM\1") != 0) {
+      if (!r->src.err.empty()) { r->err = r->src.err + " in '" + r->path + "'"; return MM_ERR_PARSE; }   // (nothing could be read at all)
       r->err = "Problem with file '" + r->path + "': file does not look like a BAM file (missing magic string, got '" + magic + "' instead of 'BAM\\1').";
       return MM_ERR_PARSE;
     }
@@ -1006,7 +1033,7 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n_o
   // NH travels inside the tuple; the rare value beyond the field goes to the side list (the batch ends while that list
   // still has room for a whole run of fast-path records)
   r->batch_qlo = ~0ull;
-  auto put_nh = [&](size_t i, uint32_t v) { if (v > mx) mx = v; if (v > 1 && aln[i].qid < r->batch_qlo) r->batch_qlo = aln[i].qid; if (v >= MM_ALN_NH_ESCAPE) { big[nb].index = (uint32_t) i; big[nb].nh = v; ++nb; } };
+  auto put_nh = [&](size_t i, uint32_t v) { if (v > mx) mx = v; if (v > 1 && aln[i].qid < r->batch_qlo) r->batch_qlo = aln[i].qid; if (v >= MM_ALN_NH_ESCAPE && nb < big_cap) { big[nb].index = (uint32_t) i; big[nb].nh = v; ++nb; } };
   while (n < cap && !r->over && nb + 33 <= big_cap) {
     // BGZF input, records framed and parsed by the pipe's threads: finish them in file order
     if (r->parsed_mode && !(r->have_record && r->alt_next < r->alts.size())) {
@@ -1018,8 +1045,13 @@ extern "C" int mm_reader_next(mm_reader *r, mm_aln *aln, size_t cap, size_t *n_o
           const size_t stop = std::min(pb->n_recs, k + (cap - n));
           const uint8_t *base = pb->data.data();
           // the read-name ids of a long run come from all threads at once (QidSpace::resolve_run), those of a short one from here
-          size_t run_end = k;
-          while (run_end < stop && (recs[run_end].flags & PR_FAST)) ++run_end;
+          // (the run also ends where the NH side list would be full: every record with an NH beyond the tuple's field takes an entry,
+          // and the caller's list has big_cap of them - the batch then ends early, the rest of the run opens the next one)
+          size_t run_end = k, esc = 0;
+          while (run_end < stop && (recs[run_end].flags & PR_FAST)) {
+            if (recs[run_end].nh >= MM_ALN_NH_ESCAPE) { if (nb + esc == big_cap) break; ++esc; }
+            ++run_end;
+          }
           const size_t k0 = k;
           const bool par = run_end - k0 >= 8192 && r->src.pipe->n_threads > 1;
           if (par) {

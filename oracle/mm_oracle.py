@@ -386,17 +386,19 @@ def write_bam_bytes(path: str, chroms: Sequence[Tuple[str, int]], body: bytes, l
         f.write(co.flush())
 
 
-def write_bgzf(path: str, payload: bytes, level: int = 1, block: int = 0xff00) -> None:
+def write_bgzf(path: str, payload: bytes, level: int = 1, block: int = 0xff00, extra_before: bytes = b"", extra_after: bytes = b"") -> None:
     """BGZF container (the blocked gzip real BAM files use): independent <= 64 KiB gzip members with a 'BC' extra field
-    holding the compressed block size, plus the empty end-of-file block."""
+    holding the compressed block size, plus the empty end-of-file block.  extra_before / extra_after: further (well-formed)
+    subfields of the gzip extra field around 'BC' - the SAM specification allows them."""
     import zlib
     with open(path, "wb") as f:
         def member(chunk: bytes):
             co = zlib.compressobj(level, zlib.DEFLATED, -15)
             comp = co.compress(chunk) + co.flush()
-            bsize = len(comp) + 25                      # total block size - 1
-            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
-                    struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+            xlen = 6 + len(extra_before) + len(extra_after)
+            bsize = len(comp) + 12 + xlen + 8 - 1       # total block size - 1
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", xlen) + extra_before + b"BC\x02\x00" + struct.pack("<H", bsize) +
+                    extra_after + comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
         for o in range(0, len(payload), block):
             member(payload[o:o + block])
         member(b"")
