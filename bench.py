@@ -24,15 +24,25 @@ Workloads (BASELINE.json configs):
       vicinity (-d/-D 1000), -l 50, under -s U: the reference's parser rejects -s FR, so -s U is
       the only setting of this configuration that has an oracle.
   c5: NH = 1..100 groups, -y ratio, HS38-scale annotation.
---scaling weak (default): every rank runs K batches of 2^B tuples; strong: the K x 2^B tuples of the job are split over the
-ranks (every rank runs K batches of 2^B / N tuples).
+--scaling weak (default): every rank runs K batches of 2^B tuples of a stream of its own.  strong: ONE seeded stream of K batches of
+2^B tuples is dealt out over the ranks the way the product shards an input (mm_partition: by read name, qid mod N, names renumbered
+qid / N, file order kept - every hit of a read on one GPU, which the multi-hit countdown needs, mmannot.cpp:1669-1701; -y ratio:
+consecutive blocks of the stream, its double sums being file-order dependent, mmannot.cpp:1730), so the job's table - and its
+`table_digest` - is the same for every N.
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (python -m torch.distributed.run as a
+CHILD process, before anything in this process touches the GPU) and exits with their status; under a launcher, a WORLD_SIZE that
+disagrees with --gpus is an error.  With more than one rank, rank 0 re-runs every rank's share on its own GPU afterwards (untimed)
+and checks the merged table and counters against it (`merge_check`).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -79,6 +89,14 @@ def main():
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
     args = ap.parse_args()
 
+    # N > 1 asked for plainly (no launcher): start the N ranks as a child process - this process has not touched the GPU (and will not)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                         f"launch with --nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a launcher)\n")
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
     import mmannot_amd as mm
@@ -105,7 +123,8 @@ def main():
         else:
             dist.init_process_group(backend)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    n_joined = dist.get_world_size() if multi else 1          # ranks that really joined the group: what `n_gpus` reports
+    assert n_joined == args.gpus, f"{n_joined} ranks joined the process group, --gpus says {args.gpus}"
 
     # ---------------- annotation (same on every rank) -> device index
     wl = dict(WORKLOADS[args.workload])
@@ -122,46 +141,82 @@ def main():
     ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy, stream=stream,
                      defer_ratio=(strategy == "ratio" and multi))
 
-    # ---------------- inputs: W+K batches per rank (rank-local stream, rank-local read-name ids)
-    B = 1 << args.batch_log2
-    if args.scaling == "strong":
-        B = max(1 << 16, B // world)     # the job's K x 2^B tuples split over the ranks
+    # ---------------- inputs: W+K batches per rank
+    # weak: a stream of this rank's own (seed + rank), rank-local read-name ids.
+    # strong: ONE stream (the job), dealt out as the product does it - default / unique: by read name, qid mod N, names renumbered
+    #   qid / N, file order kept (mm_partition); ratio: rank r holds the r-th consecutive block of the stream.
+    Bg = 1 << args.batch_log2                      # tuples per batch of a stream
     nb = args.warmup + args.steps
+    strong = args.scaling == "strong"
+    by_name = strong and strategy != "ratio"
     chr_len = np.ascontiguousarray(an.chr_len, dtype=np.int64)
     single = nh_max == 1
-    alns = []
-    for s in range(nb):
-        a = torch.empty((B, 4), dtype=torch.int32, device=dev)
-        p = _lib.SynthParams(args.seed * 1000003 + rank, s * B, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
-        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), B, C.byref(p), stream))
-        alns.append(a)
-    torch.cuda.synchronize()
-    # exclusive bound of the read-name ids of the whole stream (names are numbered along the logical order of the hits; the scatter
-    # permutes inside windows of 2^scatter tuples, so ids reach to the end of the last window touched)
-    if nh_max > 1:
-        last_l = -((-nb * B) // (1 << scatter)) * (1 << scatter)
-        qb = (last_l // (nh_max * (nh_max + 1) // 2) + 2) * nh_max + 2
-    else:
-        qb = nb * B + 2
-    total_tuples = world * nb * B
-
-    # Read-name ids of a batch: the decoder of a real input knows the smallest id among a batch's multi-hit tuples and the size of its
-    # dictionary; here both follow from the generator.  The hits of a read are spread over windows of 2^scatter tuples: inside the batch
-    # (the default), or - a window wider than a batch, e.g. --scatter-log2 28 - over many batches, which is what a coordinate-sorted
-    # file looks like (every batch then touches the names of a whole window: a wide key range, several partition passes).
     T_grp = nh_max * (nh_max + 1) // 2
     W_sc = 1 << scatter
+    job_seed = args.seed * 1000003
+
+    def gen(seed, first, n):
+        a = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        p = _lib.SynthParams(seed, first, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
+        _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), n, C.byref(p), stream))
+        return a
+
+    # read-name ids of a stream cut into batches of `bsz` tuples: the decoder of a real input knows the smallest id among a batch's
+    # multi-hit tuples and the size of its dictionary; here both follow from the generator.  The hits of a read are spread over windows
+    # of 2^scatter tuples: inside the batch (the default), or - a window wider than a batch, e.g. --scatter-log2 28 - over many
+    # batches, which is what a coordinate-sorted file looks like (every batch then touches the names of a whole window: a wide key
+    # range, several partition passes).
+    def stream_qb(n_tuples):      # exclusive bound of the read-name ids of a stream of n_tuples
+        if nh_max <= 1:
+            return n_tuples + 2
+        last_l = -((-n_tuples) // W_sc) * W_sc
+        return (last_l // T_grp + 2) * nh_max + 2
+
+    def stream_qlo(first):        # no multi-hit tuple at or behind stream position `first` has an id below this
+        return 0 if nh_max <= 1 else ((first // W_sc) * W_sc // T_grp) * nh_max
+
+    def stream_qbound(end, qb_all):   # exclusive bound of the ids seen in the stream's first `end` tuples
+        if nh_max <= 1:
+            return qb_all
+        hi = -((-end) // W_sc) * W_sc
+        return min(qb_all, (hi // T_grp + 2) * nh_max + 2)
+
+    alns, qlo_of, qbound_of = [], [], []
+    if not strong:
+        B = Bg
+        qb = stream_qb(nb * B)
+        for s_ in range(nb):
+            alns.append(gen(job_seed + rank, s_ * B, B))
+            qlo_of.append(stream_qlo(s_ * B)); qbound_of.append(stream_qbound((s_ + 1) * B, qb))
+    elif by_name:
+        qb_job = stream_qb(nb * Bg)
+        qb = qb_job // world + 2
+        for s_ in range(nb):
+            g = gen(job_seed, s_ * Bg, Bg)
+            q = g[:, 3].to(torch.int64) & 0xFFFFFFFF
+            mine = g[(q % world) == rank].contiguous()
+            mine[:, 3] = ((mine[:, 3].to(torch.int64) & 0xFFFFFFFF) // world).to(torch.int32)
+            alns.append(mine)
+            qlo_of.append(stream_qlo(s_ * Bg) // world); qbound_of.append(min(qb, stream_qbound((s_ + 1) * Bg, qb_job) // world + 2))
+            del g, q
+        B = max(1, Bg // world)
+    else:                        # strong, -y ratio: consecutive blocks
+        B = max(1 << 12, Bg // world)
+        qb = stream_qb(world * nb * B)
+        for s_ in range(nb):
+            first = (rank * nb + s_) * B
+            alns.append(gen(job_seed, first, B))
+            qlo_of.append(stream_qlo(first)); qbound_of.append(stream_qbound(first + B, qb))
+    torch.cuda.synchronize()
+    sizes = [int(a.shape[0]) for a in alns]
+    total_tuples = (world * nb * B) if (not strong or not by_name) else nb * Bg
+    job_tuples_timed = (world * args.steps * B) if (not strong or not by_name) else args.steps * Bg
 
     def qlo(step):
-        if nh_max <= 1:
-            return 0
-        return ((step * B // W_sc) * W_sc // T_grp) * nh_max
+        return qlo_of[step]
 
-    def qbound(step):   # exclusive bound of the ids seen up to and including this batch
-        if nh_max <= 1:
-            return qb
-        hi = -((-(step + 1) * B) // W_sc) * W_sc
-        return min(qb, (hi // T_grp + 2) * nh_max + 2)
+    def qbound(step):
+        return qbound_of[step]
     if nh_max > 1 and strategy == "default":
         ctr.reserve(qb)         # the per-read-name state is sized once, before any timing (a decoder that knows the number of reads)
 
@@ -177,10 +232,10 @@ def main():
             packed, bases12 = [], []
             for h in pinned16():
                 h16 = h.numpy().view(mm.ALN_DTYPE).reshape(-1)
-                base = int(h16["qid"].min())
-                out = torch.empty(B * 12, dtype=torch.uint8).pin_memory()
+                base = int(h16["qid"].min()) if len(h16) else 0
+                out = torch.empty(max(1, len(h16)) * 12, dtype=torch.uint8).pin_memory()
                 nbig = C.c_size_t(0)
-                _lib.check(_lib.lib().mm_pack12(h16.ctypes.data, B, None, 0, base, C.c_void_p(out.data_ptr()), None, 0, C.byref(nbig)))
+                _lib.check(_lib.lib().mm_pack12(h16.ctypes.data, len(h16), None, 0, base, C.c_void_p(out.data_ptr()), None, 0, C.byref(nbig)))
                 packed.append(out); bases12.append(base)
             _pinned[12] = packed
             _pinned["bases"] = bases12
@@ -196,12 +251,14 @@ def main():
         ctr.set_profiling(0)
 
         def step(s):
+            if sizes[s] == 0:
+                return
             if host is not None and pk12:
-                ctr.add_batch_host12(host[s].data_ptr(), B, _pinned["bases"][s], qbound(s), single_hit=single, qid_lo=qlo(s))
+                ctr.add_batch_host12(host[s].data_ptr(), sizes[s], _pinned["bases"][s], qbound(s), single_hit=single, qid_lo=qlo(s))
             elif host is not None:
-                ctr.add_batch_host(host[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
+                ctr.add_batch_host(host[s].data_ptr(), sizes[s], qbound(s), single_hit=single, qid_lo=qlo(s))
             else:
-                ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
+                ctr.add_batch_device(alns[s].data_ptr(), sizes[s], qbound(s), single_hit=single, qid_lo=qlo(s))
 
         for s in range(args.warmup):
             step(s)
@@ -266,29 +323,50 @@ def main():
     else:
         ctr.clear()
         for s in range(args.warmup):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
+            ctr.add_batch_device(alns[s].data_ptr(), sizes[s], qbound(s), single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         ctr.set_profiling(1)
         for s in range(args.warmup, args.warmup + n_phase):
-            ctr.add_batch_device(alns[s].data_ptr(), B, qbound(s), single_hit=single, qid_lo=qlo(s))
+            ctr.add_batch_device(alns[s].data_ptr(), sizes[s], qbound(s), single_hit=single, qid_lo=qlo(s))
         ctr.sync()
         phases_all = ctr.phase_ms()
         ctr.set_profiling(0)
 
+    # ---------------- more than one rank: is the merged result what ONE GPU gives for the same work?  Rank 0 re-runs every rank's share
+    # (untimed, resident, batch by batch from the generator) and compares tables, counters and - under -y ratio - the sums' bit patterns.
+    merge_check = None
+    if multi and rank == 0:
+        lead_ = res_host if res_host is not None else res_dev
+        merge_check = check_against_one_gpu(mm, torch, index, wl, gen, dict(strong=strong, by_name=by_name, world=world, nb=nb, B=B, Bg=Bg,
+                                                                               job_seed=job_seed, single=single, nh_max=nh_max),
+                                            (stream_qb, stream_qlo, stream_qbound), lead_[2], lead_[3], lead_[4])
+        assert merge_check["verified"], merge_check
+
     if rank == 0:
         lead = res_host if res_host is not None else res_dev
         elapsed, _, masks, sums, stats = lead
-        job = world * args.steps * B
+        job = job_tuples_timed
+        B = int(round(sum(sizes[args.warmup:]) / max(1, args.steps)))       # this rank's mean timed batch (strong scaling by name: sizes vary)
+        sharding = ("one seeded stream dealt out by read name: qid mod N, names renumbered qid / N, file order kept (as mm_partition); "
+                    "tables merged by all_gather of keys + all_reduce of counts") if by_name else \
+                   ("one seeded stream cut into N consecutive blocks, the ordered double sums chained rank to rank" if strong else
+                    ("every rank its own seeded stream; " + ("ordered double sums chained rank to rank" if strategy == "ratio"
+                                                             else "tables merged by all_gather of keys + all_reduce of counts")))
         out = {
-            "metric": "annotated alignments/sec", "value": job / elapsed, "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
+            "metric": "annotated alignments/sec", "value": job / elapsed, "unit": "alignments/s", "n_gpus": n_joined, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32/u64 (f64 only under -y ratio)", "data": "synthetic",
             "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "order_elements": len(an.config),
-                       "index_bytes": info, "sharding": "by read name, table merged by all_gather+all_reduce",
+                       "index_bytes": info, "sharding": sharding,
                        "input": f"{args.tuple_bytes}-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region" if res_host is not None
                                 else "tuples resident in HBM (--legs resident: NOT the metric of record)"},
             "stats": stats, "table_rows": int(len(masks)),
+            # sha256 over the table sorted by element set (sets, sums' bit patterns) and the seven counters: equal digests = equal results.
+            # --scaling strong: the same for every N (one stream); weak: N streams, comparable only at equal N
+            "table_digest": table_digest(masks, sums, stats),
         }
+        if merge_check is not None:
+            out["merge_check"] = merge_check
         if res_host is not None:
             h_ms, h_n = res_host[1]["h2d"]
             avg_copy_s = h_ms / max(1, h_n) / 1e3
@@ -315,13 +393,7 @@ def main():
             probe_ms, probe_n = k_ph["probe"]
             avg_probe_s = probe_ms / max(1, probe_n) / 1e3
             achieved = B_ALG_PROBE * B / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
-            traffic = None
-            pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pj):
-                try:
-                    traffic = json.load(open(pj)).get(args.workload, {}).get("k_probe_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            traffic, traffic_source = pmc_traffic(args.workload)
             # whole step against the HBM roof with SURVEY.md 8d's algorithmic bytes: 32 B per alignment (stream in + index probe), 49 B with
             # the multi-hit merge (-y default, NH > 1: + 16 B mask RMW + 8 B per group)
             b_step = 49.0 if (strategy == "default" and nh_max > 1) else 32.0
@@ -331,8 +403,8 @@ def main():
                                   "step_roofline": {"bound": "hbm", "alg_bytes_per_alignment": b_step, "achieved": step_gbs, "peak": 8000.0,
                                                     "unit": "GB/s", "frac": step_gbs / 8000.0}}
             out["roofline"] = {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "traffic": traffic, "alg_bytes_per_alignment": B_ALG_PROBE, "avg_launch_ms": avg_probe_s * 1e3,
-                               "dominant_phase": dom}
+                               "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_alignment": B_ALG_PROBE,
+                               "avg_launch_ms": avg_probe_s * 1e3, "dominant_phase": dom}
             if traffic and B == (1 << 24):     # (the counters were collected on 2^24-tuple launches) the same kernel in the bytes that really moved
                 out["roofline"]["traffic_achieved"] = traffic / avg_probe_s / 1e9
                 out["roofline"]["traffic_frac"] = traffic / avg_probe_s / 1e9 / 8000.0
@@ -352,6 +424,110 @@ def main():
     ctr.close(); index.close()
     if multi:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: the N ranks run as children of `python -m torch.distributed.run` (one process per
+    GPU, RCCL over xGMI), started from a process that has not initialised the GPU; their exit status is this process's."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def table_digest(masks, sums, stats) -> str:
+    """One hash of a job's result: rows sorted by element set (set, bit pattern of the sum) + the seven counters in Counter's order."""
+    from mmannot_amd import _lib
+    o = np.argsort(masks, kind="stable")
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(masks[o], dtype=np.uint64).tobytes())
+    h.update(np.ascontiguousarray(sums[o], dtype=np.float64).view(np.uint64).tobytes())
+    h.update(np.array([stats[k] for k in _lib.STAT_NAMES], dtype=np.uint64).tobytes())
+    return h.hexdigest()[:32]
+
+
+def mm_device_sha() -> str:
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "mmannot_amd", "csrc", "mm_device.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return "unknown"
+
+
+def pmc_traffic(workload):
+    """HBM bytes per k_probe launch from the tracked counter summary (profiles/pmc_latest.json, written by tools/prof_summary.py from
+    separate rocprofv3 --pmc passes of `bench.py --legs resident`).  The figure comes from a FILE, not from this run: it is handed out
+    only while the kernel source it was collected on is the one this run was built from (sha256 of mm_device.hip), and labelled."""
+    pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        e = json.load(open(pj)).get(workload, {})
+    except Exception:
+        return None, "no counter summary (profiles/pmc_latest.json)"
+    t = e.get("k_probe_hbm_bytes_per_launch")
+    if t is None:
+        return None, "no counter summary for this workload"
+    have, now = e.get("mm_device_sha"), mm_device_sha()
+    if have != now:
+        return None, f"stale: {e.get('source')} was collected on mm_device.hip {have}, this run is {now}"
+    return t, f"file {e.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --legs resident on mm_device.hip {have}), not this run"
+
+
+def check_against_one_gpu(mm, torch, index, wl, gen, J, qfun, masks, sums, stats):
+    """(rank 0, after the timed legs) every rank's share of the job once more on THIS GPU, one context, no collective - the merged
+    table, counters and (ratio) sum bit patterns must be the same.  What it checks is the exchange step: dist.merge_counts /
+    dist.chain_ratio over RCCL against plain addition / plain file order."""
+    stream_qb, stream_qlo, stream_qbound = qfun
+    strategy = wl["strategy"]
+    ctr = mm.Counter(index, overlap=wl["overlap"], strandedness=wl["strand"], strategy=strategy)
+    world, nb, B, Bg = J["world"], J["nb"], J["B"], J["Bg"]
+    rows, tot = {}, {}
+
+    def take():
+        ctr.flush()
+        m, s_ = ctr.getCounts()
+        for k, v in zip(m.tolist(), s_.tolist()):
+            rows[k] = rows.get(k, 0.0) + v
+        for k, v in ctr.stats().items():
+            tot[k] = tot.get(k, 0) + v
+
+    if J["strong"] and J["by_name"]:          # the job = one stream: run it whole, with its own read-name ids
+        qb = stream_qb(nb * Bg)
+        if J["nh_max"] > 1 and strategy == "default":
+            ctr.reserve(qb)
+        for s_ in range(nb):
+            a = gen(J["job_seed"], s_ * Bg, Bg)
+            ctr.add_batch_device(a.data_ptr(), Bg, stream_qbound((s_ + 1) * Bg, qb), single_hit=J["single"], qid_lo=stream_qlo(s_ * Bg))
+            ctr.sync()
+        take()
+        how = "the whole stream on one GPU"
+    elif strategy == "ratio":                 # file order = rank order: one context, never cleared
+        for r in range(world):
+            for s_ in range(nb):
+                first = (r * nb + s_) * B if J["strong"] else s_ * B
+                a = gen(J["job_seed"] + (0 if J["strong"] else r), first, B)
+                ctr.add_batch_device(a.data_ptr(), B, 1, single_hit=J["single"])
+                ctr.sync()
+        take()
+        how = "every rank's block in rank order through one context"
+    else:                                     # weak: N independent streams - tables and counters add up
+        qb = stream_qb(nb * B)
+        if J["nh_max"] > 1 and strategy == "default":
+            ctr.reserve(qb)
+        for r in range(world):
+            ctr.clear()
+            for s_ in range(nb):
+                a = gen(J["job_seed"] + r, s_ * B, B)
+                ctr.add_batch_device(a.data_ptr(), B, stream_qbound((s_ + 1) * B, qb), single_hit=J["single"], qid_lo=stream_qlo(s_ * B))
+                ctr.sync()
+            take()
+        how = "every rank's stream on one GPU, tables and counters added on the host"
+    ctr.close()
+    got = dict(zip(masks.tolist(), np.ascontiguousarray(sums, dtype=np.float64).view(np.uint64).tolist()))
+    want = {k: int(np.float64(v).view(np.uint64)) for k, v in rows.items()}
+    ok = got == want and {k: int(v) for k, v in stats.items()} == tot
+    return {"verified": bool(ok), "reference": how, "rows": len(want)}
 
 
 def bind_to_gpu_numa_node(device_index: int):
@@ -451,7 +627,7 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     read_len, nh_max, scatter, strategy = wl["read_len"], wl["nh_max"], wl["scatter"], wl["strategy"]
     flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else []) + (["-y", strategy] if strategy != "default" else [])
     S = host_cores()
-    n = 1 << (21 if S <= 32 else 20)     # bounded sample: S shards, about 1-2 s of reference time each
+    n = 1 << (22 if S <= 32 else 21)     # bounded sample: S shards of 2-3 s of reference work each (3x and more the subtracted loading time)
     d = tempfile.mkdtemp(prefix="mmbench")
     gtf = os.path.join(d, "a.gtf"); open(gtf, "w").write(synth.gtf_text(an))
     cfgp = os.path.join(d, "c.cfg"); open(cfgp, "w").write(synth.config_text(an.shape))

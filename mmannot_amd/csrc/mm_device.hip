@@ -209,21 +209,25 @@ __device__ __forceinline__ u32 hash64(u64 k) {
   return (u32) (k >> 40);
 }
 
-struct LdsTable {
-  u64 key[LT_CAP];
-  u32 cnt[LT_CAP];
-  u32 slot[LT_CAP];   // cached slot of the set in the global table (NO_KEY = not looked up yet)
+template <u32 CAP>
+struct LdsTableT {
+  u64 key[CAP];
+  u32 cnt[CAP];
+  u32 slot[CAP];   // cached slot of the set in the global table (NO_KEY = not looked up yet)
   u32 single[64];     // counts of the single-element sets {e} (by far the most frequent): no hashing
   u32 singleSlot[64];
 };
+typedef LdsTableT<LT_CAP> LdsTable;
 
-__device__ __forceinline__ void lds_table_init(LdsTable &t) {
-  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; t.slot[i] = NO_KEY; }
+template <u32 CAP>
+__device__ __forceinline__ void lds_table_init(LdsTableT<CAP> &t) {
+  for (u32 i = threadIdx.x; i < CAP; i += blockDim.x) { t.key[i] = 0; t.cnt[i] = 0; t.slot[i] = NO_KEY; }
   if (threadIdx.x < 64) { t.single[threadIdx.x] = 0; t.singleSlot[threadIdx.x] = NO_KEY; }
 }
 
-__device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
-  u32 h = hash64(m) & (LT_CAP - 1);
+template <u32 CAP>
+__device__ __forceinline__ bool lds_table_add(LdsTableT<CAP> &t, u64 m, u32 inc) {
+  u32 h = hash64(m) & (CAP - 1);
   for (u32 p = 0; p < LT_MAXPROBE; ++p) {
     u64 k = *(volatile u64 *) &t.key[h];
     if (k == 0) {
@@ -231,7 +235,7 @@ __device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
       if (k == 0) k = m;
     }
     if (k == m) { atomicAdd(&t.cnt[h], inc); return true; }
-    h = (h + 1) & (LT_CAP - 1);
+    h = (h + 1) & (CAP - 1);
   }
   return false;
 }
@@ -239,8 +243,9 @@ __device__ __forceinline__ bool lds_table_add(LdsTable &t, u64 m, u32 inc) {
 __device__ __forceinline__ u32 gt_find_or_insert(const struct GlobalTable &g, u64 m);
 
 // slot of set m in the global table, through the workgroup's LDS table (one global lookup per set and workgroup)
-__device__ __forceinline__ u32 lds_cached_slot(LdsTable &t, const struct GlobalTable &g, u64 m) {
-  u32 h = hash64(m) & (LT_CAP - 1);
+template <u32 CAP>
+__device__ __forceinline__ u32 lds_cached_slot(LdsTableT<CAP> &t, const struct GlobalTable &g, u64 m) {
+  u32 h = hash64(m) & (CAP - 1);
   for (u32 p = 0; p < LT_MAXPROBE; ++p) {
     u64 k = *(volatile u64 *) &t.key[h];
     if (k == 0) {
@@ -252,18 +257,20 @@ __device__ __forceinline__ u32 lds_cached_slot(LdsTable &t, const struct GlobalT
       if (sl == NO_KEY) { sl = gt_find_or_insert(g, m); t.slot[h] = sl; }
       return sl;
     }
-    h = (h + 1) & (LT_CAP - 1);
+    h = (h + 1) & (CAP - 1);
   }
   return gt_find_or_insert(g, m);
 }
 
 // per-lane: count one occurrence of set m / get the global slot of set m (no wave-level serialisation)
 __device__ __forceinline__ void gt_add(const struct GlobalTable &g, u64 m, u64 inc);
-__device__ __forceinline__ void count_set(LdsTable &t, const struct GlobalTable &g, u64 m) {
+template <u32 CAP>
+__device__ __forceinline__ void count_set(LdsTableT<CAP> &t, const struct GlobalTable &g, u64 m) {
   if ((m & (m - 1)) == 0) atomicAdd(&t.single[__ffsll((long long) m) - 1], 1u);
   else if (!lds_table_add(t, m, 1)) gt_add(g, m, 1);
 }
-__device__ __forceinline__ u32 slot_of_set(LdsTable &t, const struct GlobalTable &g, u64 m) {
+template <u32 CAP>
+__device__ __forceinline__ u32 slot_of_set(LdsTableT<CAP> &t, const struct GlobalTable &g, u64 m) {
   if ((m & (m - 1)) == 0) {
     const int e = __ffsll((long long) m) - 1;
     u32 sl = *(volatile u32 *) &t.singleSlot[e];
@@ -317,13 +324,14 @@ __device__ __forceinline__ void gt_add(const GlobalTable &g, u64 m, u64 inc) {
   if (s != NO_KEY) atomicAdd(&g.cnt[s], inc);
 }
 
-__device__ __forceinline__ void lds_table_flush(LdsTable &t, const GlobalTable &g) {
+template <u32 CAP>
+__device__ __forceinline__ void lds_table_flush(LdsTableT<CAP> &t, const GlobalTable &g) {
   if (threadIdx.x < 64 && t.single[threadIdx.x]) {
     const u32 sl = t.singleSlot[threadIdx.x];
     if (sl != NO_KEY) atomicAdd(&g.cnt[sl], (u64) t.single[threadIdx.x]);
     else gt_add(g, 1ull << threadIdx.x, (u64) t.single[threadIdx.x]);
   }
-  for (u32 i = threadIdx.x; i < LT_CAP; i += blockDim.x) {
+  for (u32 i = threadIdx.x; i < CAP; i += blockDim.x) {
     const u64 k = t.key[i];
     const u32 c = t.cnt[i];
     if (k && c) {
@@ -424,6 +432,10 @@ __device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c
 #define REC_TYPE(y) (((y) >> REC_LEN_BITS) & 63u)
 #define REC_OKBIT 28
 #define REC_LONG (1u << 30)
+// fast slots (4-byte bin-relative records, see mm_index_create): usable up to this bin shift - beyond it the saturating length field
+// (24 - shift - 1 bits) is shorter than a bin
+#define FS_MAX_SHIFT 11
+#define FS_OVERFLOW 0x80000000u     // header: more than 7 records - the tuple takes the 8-byte slots
 
 template <int OVL>
 __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, int s, int e, int rstrand, u32 &o, int &ie) {
@@ -729,6 +741,97 @@ __global__ __launch_bounds__(256) void k_expand12(const u32 *__restrict__ pk, in
   }
 }
 
+// ----------------------------------------------------------------------------- what every probe kernel does with a tuple's element set
+// addCount's per-hit half (mmannot.cpp:1666-1668, 1703-1738) and the hand-over of multi-hit records to the grouping pipeline
+// (mmannot.cpp:1669-1702), shared by k_probe (the general walk), k_probe_fast (round 3: pipelined walk over the 32-byte slots) and
+// k_probe_list (the tuples k_probe_fast passes on).  Wave-level ballots inside: every lane of the wave has to come through here,
+// lanes without a tuple with processed = false.
+struct ProbeAcc {
+  // the six per-hit counters of addCount, two 16-bit fields to a register, kept per lane and summed once at the end (a lane sees at
+  // most 2^32 / (2048 x 256) = 8192 tuples): a ballot and a population count per counter and tuple was a tenth of the kernel's
+  // instructions, and the probe is bound by instruction issue (SQ_ACTIVE_INST_VALU = 73 % of the SIMDs' issue slots, round 2)
+  u32 cHU = 0, cAM = 0, cRN = 0;   // hits | unassigned << 16;  ambiguous | multiple << 16;  reads | unique << 16
+  u32 qinv = 0, qmax = 0, bigNh = 0;
+};
+enum { HIST_NONE = 0, HIST_LDS = 1, HIST_GLOBAL = 2 };   // where the first partition pass's digit counts of a tile go: nowhere / the workgroup's LDS row / straight to hist[] with atomics (k_probe_list)
+template <u32 CAP>
+__device__ __forceinline__ void tuple_tail(const bool grouped_strategy, const bool ratio, const bool randomStrategy, const int histMode, LdsTableT<CAP> &T,
+                                           u32 *sHist, u32 *__restrict__ hist, const u32 nblk, const GlobalTable &G, const u32 qlo, const u32 lane,
+                                           const size_t i, const int4 a, const u32 nh, const bool processed, const u64 mask, ProbeAcc &A, u32 &key, u32 &pay) {
+  const int np = __popcll(mask);
+  bool grouped = processed && grouped_strategy && nh > 1;
+  // a multi-hit tuple below the caller's qid_lo: the launches (and, fused, the histogram's origin) were sized on that promise -
+  // the batch is refused, and the tuple stays out of the pipeline so that nothing is written out of bounds
+  if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
+  A.cHU += (processed ? 1u : 0u) | ((processed && np == 0) ? 0x10000u : 0u);
+  A.cAM += ((processed && np > 1) ? 1u : 0u) | (grouped ? 0x10000u : 0u);
+  if (histMode == HIST_LDS && !ratio) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
+    const u64 gm = __ballot(grouped);
+    if (gm) {
+      const u32 d = min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u);   // (an id outside the promised range is an error anyway)
+      const int l0 = __ffsll((long long) gm) - 1;
+      const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
+      const u64 same = __ballot(grouped && d == d0);
+      if ((int) lane == l0) atomicAdd(&sHist[d0], (u32) __popcll(same));
+      else if (grouped && d != d0) atomicAdd(&sHist[d], 1u);
+    }
+  } else if (histMode == HIST_GLOBAL && !ratio && grouped)
+    atomicAdd(&hist[(size_t) min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u) * nblk + (u32) (i / RS_TILE)], 1u);
+  A.cRN += ((processed && !grouped) ? 1u : 0u) | ((processed && np == 1 && nh == 1) ? 0x10000u : 0u);   // mmannot.cpp:1737, 1668
+  const bool counted = processed && !grouped && mask != 0 && !randomStrategy;   // mmannot.cpp:1704 (random: the caller decides)
+  key = NO_KEY; pay = GT_NO_SLOT;
+  if (grouped) {
+    key = (u32) a.w;
+    A.qinv = max(A.qinv, ~key); A.qmax = max(A.qmax, key);
+    if (nh >= 0xFFFFu) A.bigNh = 1;
+  }
+  // counting / slot lookup, per lane through the workgroup's LDS tables:
+  //   per-hit branch (default/unique): the set is counted now;
+  //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
+  //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
+  if (counted && !ratio) count_set(T, G, mask);
+  if (ratio && counted) { key = slot_of_set(T, G, mask); if (key != NO_KEY && key >= RS_BINS) A.bigNh = 1; }   // (-y ratio: the flag means "wide key")
+  // -y ratio: the one-pass sort's digit is the slot itself (a handful of rows take most hits: equal digits are counted together);
+  // should a slot of the batch turn out not to be below RS_BINS, this histogram is void and k_rs_hist counts 8-bit digits instead
+  if (histMode == HIST_LDS && ratio) wave_hist_add<0>(sHist, key & (RS_BINS - 1u), key != NO_KEY, true);
+  else if (histMode == HIST_GLOBAL && ratio) { if (key != NO_KEY) atomicAdd(&hist[(size_t) (key & (RS_BINS - 1u)) * nblk + (u32) (i / RS_TILE)], 1u); }
+  else if (grouped && mask != 0) {
+    if ((mask & (mask - 1)) == 0) pay = (u32) (__ffsll((long long) mask) - 1);   // one element: the payload names it
+    else pay = slot_of_set(T, G, mask) & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
+  }
+}
+
+// end of a probe kernel: the per-lane counters and key range -> the context's counters and the batch scalars; the workgroup's counts -> the table
+template <u32 CAP>
+__device__ __forceinline__ void probe_finish(const bool grouped_strategy, const bool ratio, const bool haveKey, ProbeAcc &A, u32 *sstat, u32 *sq, LdsTableT<CAP> &T,
+                                             const GlobalTable &G, u64 *__restrict__ stats, u32 *__restrict__ info) {
+  const u32 lane = threadIdx.x & 63;
+  if (grouped_strategy && haveKey) {
+    for (int off = 32; off > 0; off >>= 1) { A.qinv = max(A.qinv, __shfl_down(A.qinv, off)); A.qmax = max(A.qmax, __shfl_down(A.qmax, off)); A.bigNh |= __shfl_down(A.bigNh, off); }
+    if (lane == 0) { atomicMax(&sq[0], A.qinv); atomicMax(&sq[1], A.qmax); if (A.bigNh) atomicOr(&sq[2], 1u); }
+  }
+  if (ratio && haveKey && __ballot(A.bigNh != 0) && lane == 0) atomicOr(&sq[2], 1u);
+  {
+    u32 c[6] = {A.cHU & 0xFFFFu, A.cHU >> 16, A.cAM & 0xFFFFu, A.cAM >> 16, A.cRN & 0xFFFFu, A.cRN >> 16};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_down(c[k], off);
+    if (lane == 0) {
+      atomicAdd(&sstat[MM_STAT_HITS], c[0]); atomicAdd(&sstat[MM_STAT_UNASSIGNED], c[1]);
+      atomicAdd(&sstat[MM_STAT_AMBIGUOUS], c[2]); atomicAdd(&sstat[MM_STAT_MULTIPLE], c[3]);
+      atomicAdd(&sstat[MM_STAT_READS], c[4]); atomicAdd(&sstat[MM_STAT_UNIQUE], c[5]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
+  if (grouped_strategy && haveKey && threadIdx.x == 0) {
+    if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
+    if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
+    if (sq[2]) atomicOr(&info[INFO_BIGNH], 1u);
+  }
+  if (ratio && haveKey && threadIdx.x == 0 && sq[2]) atomicOr(&info[INFO_WIDEKEY], 1u);
+  lds_table_flush(T, G);
+}
+
 // ----------------------------------------------------------------------------- k_probe
 // One lane per alignment, grid-stride over the batch.  Per alignment: scan+getFirst, the
 // three per-hit counters of addCount (mmannot.cpp:1666-1668), then either
@@ -769,12 +872,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
   if (threadIdx.x < 3) sq[threadIdx.x] = 0;
   if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) sHist[d] = 0;
   __syncthreads();
-  u32 qinv = 0, qmax = 0, bigNh = 0;
   const u32 lane = threadIdx.x & 63;
-  // the six per-hit counters of addCount, two 16-bit fields to a register, kept per lane and summed once at the end (a lane sees at
-  // most 2^32 / (2048 x 256) = 8192 tuples): a ballot and a population count per counter and tuple was a tenth of the kernel's
-  // instructions, and the probe is bound by instruction issue (SQ_ACTIVE_INST_VALU = 73 % of the SIMDs' issue slots, round 2)
-  u32 cHU = 0, cAM = 0, cRN = 0;   // hits | unassigned << 16;  ambiguous | multiple << 16;  reads | unique << 16
+  ProbeAcc A;
   u32 walked = 0;
   const bool grouped_strategy = V ? (VAR == PV_GROUPS || VAR == PV_GROUPS_HIST) : (P.strategy == MM_STRAT_DEFAULT);
   const bool ratio = V ? (VAR == PV_RATIO || VAR == PV_RATIO_HIST) : (P.strategy == MM_STRAT_RATIO);
@@ -795,45 +894,8 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
     const bool processed = valid && !(uniqueOnly && nh != 1);  // mmannot.cpp:1773
     u64 mask = 0;
     if (processed) mask = probe_tuple<OVL>(P, useSlots, chrSlot, sLine, a, walked);
-    const int np = __popcll(mask);
-    bool grouped = processed && grouped_strategy && nh > 1;
-    // a multi-hit tuple below the caller's qid_lo: the launches (and, fused, the histogram's origin) were sized on that promise -
-    // the batch is refused, and the tuple stays out of the pipeline so that nothing is written out of bounds
-    if (grouped && (u32) a.w < qlo) { atomicCAS(G.err, 0u, (u32) ERR_QID_LO); grouped = false; }
-    cHU += (processed ? 1u : 0u) | ((processed && np == 0) ? 0x10000u : 0u);
-    cAM += ((processed && np > 1) ? 1u : 0u) | (grouped ? 0x10000u : 0u);
-    if (useHist && !ratio) {   // (wave-uniform) the wave's records mostly share one bucket: count those once, the others one by one
-      const u64 gm = __ballot(grouped);
-      if (gm) {
-        const u32 d = min(((u32) a.w - qlo) >> LEAF_BITS, RS_BINS - 1u);   // (an id outside the promised range is an error anyway)
-        const int l0 = __ffsll((long long) gm) - 1;
-        const u32 d0 = (u32) __builtin_amdgcn_readlane((int) d, l0);
-        const u64 same = __ballot(grouped && d == d0);
-        if ((int) lane == l0) atomicAdd(&sHist[d0], (u32) __popcll(same));
-        else if (grouped && d != d0) atomicAdd(&sHist[d], 1u);
-      }
-    }
-    cRN += ((processed && !grouped) ? 1u : 0u) | ((processed && np == 1 && nh == 1) ? 0x10000u : 0u);   // mmannot.cpp:1737, 1668
-    const bool counted = processed && !grouped && mask != 0 && !randomStrategy;   // mmannot.cpp:1704 (random: the caller decides)
-    u32 key = NO_KEY, pay = GT_NO_SLOT;
-    if (grouped) {
-      key = (u32) a.w;
-      qinv = max(qinv, ~key); qmax = max(qmax, key);
-      if (nh >= 0xFFFFu) bigNh = 1;
-    }
-    // counting / slot lookup, per lane through the workgroup's LDS tables:
-    //   per-hit branch (default/unique): the set is counted now;
-    //   -y ratio: the set's table slot becomes the sort key of the ordered accumulation;
-    //   multi-hit branch: the slot travels with the record so that k_chunk_default streams.
-    if (counted && !ratio) count_set(T, G, mask);
-    if (ratio && counted) { key = slot_of_set(T, G, mask); if (key != NO_KEY && key >= RS_BINS) bigNh = 1; }   // (-y ratio: the flag means "wide key")
-    // -y ratio: the one-pass sort's digit is the slot itself (a handful of rows take most hits: equal digits are counted together);
-    // should a slot of the batch turn out not to be below RS_BINS, this histogram is void and k_rs_hist counts 8-bit digits instead
-    if (useHist && ratio) wave_hist_add<0>(sHist, key & (RS_BINS - 1u), key != NO_KEY, true);
-    else if (grouped && mask != 0) {
-      if ((mask & (mask - 1)) == 0) pay = (u32) (__ffsll((long long) mask) - 1);   // one element: the payload names it
-      else pay = slot_of_set(T, G, mask) & 0xFFFFu;   // (NO_KEY, table full: error flag raised, the result is refused)
-    }
+    u32 key, pay;
+    tuple_tail(grouped_strategy, ratio, randomStrategy, useHist ? HIST_LDS : HIST_NONE, T, sHist, hist, nblk, G, qlo, lane, i, a, nh, processed, mask, A, key, pay);
     if (valid) {
       if (haveKey) {
         gkey[i] = key;                       // read again right away by the first sort pass: keep these cacheable
@@ -842,39 +904,17 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe(const ProbeParams P
       if (keepSets) st_stream(hm + i, processed ? mask : ~0ull);   // (parity / side channels only, see k_probe_sets)
     }
   }
-  if (grouped_strategy && haveKey) {
-    for (int off = 32; off > 0; off >>= 1) { qinv = max(qinv, __shfl_down(qinv, off)); qmax = max(qmax, __shfl_down(qmax, off)); bigNh |= __shfl_down(bigNh, off); }
-    if (lane == 0) { atomicMax(&sq[0], qinv); atomicMax(&sq[1], qmax); if (bigNh) atomicOr(&sq[2], 1u); }
-  }
-  if (ratio && haveKey && __ballot(bigNh != 0) && lane == 0) atomicOr(&sq[2], 1u);
-  {
-    u32 c[6] = {cHU & 0xFFFFu, cHU >> 16, cAM & 0xFFFFu, cAM >> 16, cRN & 0xFFFFu, cRN >> 16};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_down(c[k], off);
-    if (lane == 0) {
-      atomicAdd(&sstat[MM_STAT_HITS], c[0]); atomicAdd(&sstat[MM_STAT_UNASSIGNED], c[1]);
-      atomicAdd(&sstat[MM_STAT_AMBIGUOUS], c[2]); atomicAdd(&sstat[MM_STAT_MULTIPLE], c[3]);
-      atomicAdd(&sstat[MM_STAT_READS], c[4]); atomicAdd(&sstat[MM_STAT_UNIQUE], c[5]);
-    }
-  }
   if (!V && P.keep) {
     // total candidates visited (profiling aid)
     u32 w = walked;
     for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
     if (lane == 0) atomicAdd(&walkstat[0], (u64) w);
   }
-  __syncthreads();
-  if (threadIdx.x < MM_N_STATS && sstat[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (u64) sstat[threadIdx.x]);
   // (the host has zeroed hist: a tile's names fall into a few of the 512 buckets in most inputs, and each count is a store of its own
   // into another row - writing all 512 was 6 % of the kernel)
+  __syncthreads();
   if (useHist) for (u32 d = threadIdx.x; d < RS_BINS; d += blockDim.x) if (sHist[d]) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
-  if (grouped_strategy && haveKey && threadIdx.x == 0) {
-    if (sq[0]) atomicMax(&info[INFO_QINV], sq[0]);
-    if (sq[1]) atomicMax(&info[INFO_QMAX], sq[1]);
-    if (sq[2]) atomicOr(&info[INFO_BIGNH], 1u);
-  }
-  if (ratio && haveKey && threadIdx.x == 0 && sq[2]) atomicOr(&info[INFO_WIDEKEY], 1u);
-  lds_table_flush(T, G);
+  probe_finish(grouped_strategy, ratio, haveKey, A, sstat, sq, T, G, stats, info);
 }
 
 // The element set of a multi-hit record normally travels in 16 bits of its sort payload.  A batch holding an NH >= 65535 cannot
@@ -2021,6 +2061,11 @@ struct mm_index {
   int sshift = 0;
   u32 reach = 0;
   size_t n_slots = 0, n_flat = 0;
+  // fast index (round 3): the same bins as 32-byte slots of 4-byte bin-relative records + a bitmap of the non-empty ones; NULL when the
+  // bin width does not allow the encoding (see FS_* below)
+  uint4 *d_fslots = nullptr;
+  u32 *d_fbits = nullptr;
+  u32 fLmax = 0;           // longest read the fast slots answer exactly
   u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
   u64 lineMask[64];
 };
@@ -2196,6 +2241,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   std::vector<u32> slotBits;
   std::vector<uint2> flat;
   std::vector<int> longEnd;
+  std::vector<uint4> fslots;
+  std::vector<u32> fbits;
   {
     // Bin width.  Bins holding more than 7 records leave the one-sector fast path (their list continues in `flat`),
     // so the widest bin width is chosen whose share of such bins stays below 2 %, among the widths whose table (64 B
@@ -2286,6 +2333,51 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       const u32 n = std::min<u32>(total, 7u);
       for (u32 r = 0; r < n; ++r) { w[2 + 2 * r] = flat[off[k] + r].x; w[3 + 2 * r] = flat[off[k] + r].y; }
     }
+    // ---- fast slots (k_probe_fast): per bin 32 bytes = header + up to 7 records of 4 bytes, relative to the bin's first base.
+    //   record = element:6 << 26 | ok('+' read):1 << 25 | ok('-' read):1 << 24 | payload:24
+    //   payload of an interval open at the bin's left edge (the first nA records) = min(end - binStart, 2^24 - 1);
+    //   payload of one starting in the bin, or in the `reach` bases behind it = (start - binStart) : sshift + 1 bits | min(end - start, FS_LSAT) above.
+    // A saturated field says "at least": the kernel sends only reads to these slots that end before any saturated end could matter
+    // (read length <= fLmax = FS_LSAT - W, start inside the chromosome's bins), so every test stays exact.  Intervals that end before the
+    // bin starts cannot pass for a read with end >= start and are left out.  More than 7 records: the overflow bit (the tuple then takes
+    // the 8-byte slots above, as do reads that are too long, span more bins, have no CIGAR operations, or need the second selection pass).
+    if (sh <= FS_MAX_SHIFT) {
+      const u32 lenBits = 24u - (u32) (sh + 1), LSAT = (1u << lenBits) - 1u;
+      ix->fLmax = LSAT - W;
+      fslots.assign(ns * 2, make_uint4(0u, 0u, 0u, 0u));
+      fbits.assign((ns + 31) / 32 + 1, 0u);
+      for (int c = 0; c < n_chromosomes; ++c) {
+        if (!seen[c]) continue;
+        for (u32 b = 0; b < sN[c]; ++b) {
+          const u64 k = (u64) sBase[c] + b;
+          const int64_t binStart = (int64_t) b << sh;
+          u32 rec[7], n = 0, nA = 0;
+          bool ovf = false;
+          const u32 total = nAct[k] + nIv[k] + nOvh[k];
+          for (u32 r = 0; r < total; ++r) {
+            const uint2 fr = flat[off[k] + r];
+            const int64_t is = (int64_t) fr.x;
+            const u32 flen = fr.y & REC_LEN_MASK;
+            const int64_t ie = (fr.y & REC_LONG) ? (int64_t) longEnd[flen] : is + (int64_t) flen;
+            const u32 head = (REC_TYPE(fr.y) << 26) | (((fr.y >> (REC_OKBIT + 1)) & 1u) << 25) | (((fr.y >> REC_OKBIT) & 1u) << 24);
+            u32 payload;
+            if (r < nAct[k]) {
+              if (ie < binStart) continue;
+              payload = (u32) std::min<int64_t>(ie - binStart, 0xFFFFFF);
+            } else {
+              payload = (u32) (is - binStart) | ((u32) std::min<int64_t>(ie - is, (int64_t) LSAT) << (sh + 1));
+            }
+            if (n == 7) { ovf = true; break; }
+            if (r < nAct[k]) ++nA;
+            rec[n++] = head | payload;
+          }
+          u32 *w = (u32 *) &fslots[k * 2];
+          if (ovf) { w[0] = FS_OVERFLOW; n = 0; }
+          else { w[0] = nA | (n << 4); for (u32 r = 0; r < n; ++r) w[1 + r] = rec[r]; }
+          if (ovf || n) fbits[k >> 5] |= 1u << (k & 31);
+        }
+      }
+    }
     u64 nonEmpty = 0;
     for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k] + nOvh[k]) ? 1 : 0;
     if ((double) (ns - nonEmpty) < 0.33 * (double) ns) slotBits.clear();
@@ -2312,7 +2404,9 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       (e = up((void **) &ix->d_flat, flat.data(), flat.size() * sizeof(uint2))) != hipSuccess ||
       (!slotBits.empty() && (e = up((void **) &ix->d_slotBits, slotBits.data(), slotBits.size() * sizeof(u32))) != hipSuccess) ||
       (e = up((void **) &ix->d_chrSlot, chrSlot.data(), (size_t) n_chromosomes * sizeof(uint2))) != hipSuccess ||
-      (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess) {
+      (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess ||
+      (!fslots.empty() && ((e = up((void **) &ix->d_fslots, fslots.data(), fslots.size() * sizeof(uint4))) != hipSuccess ||
+                           (e = up((void **) &ix->d_fbits, fbits.data(), fbits.size() * sizeof(u32))) != hipSuccess))) {
     mm_index_destroy(ix);
     return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
   }
@@ -2324,7 +2418,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
-  (void) hipFree(ix->d_slotBits);
+  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits);
   delete ix;
 }
 

@@ -28,6 +28,8 @@ def test_single_rank_contract(gpu_lib):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert isinstance(r["traffic_source"], str) and (r["traffic"] is None or "file" in r["traffic_source"])   # a counter figure by file says so
+    assert len(d["table_digest"]) == 32 and "merge_check" not in d
     assert d["value"] > 0 and d["stats"]["nHits"] == 4 * (1 << 20)
     # `value` is the rate from pinned host tuples (copies inside the timed region); the HBM-resident rate is reported beside it
     h, k = d["h2d"], d["kernel_only"]
@@ -38,45 +40,72 @@ def test_single_rank_contract(gpu_lib):
     assert p["value"] > 0 and p["link_bytes_per_alignment"] == 12.0
 
 
-@pytest.mark.timeout(900)
-def test_two_ranks_share_one_gpu_gloo(gpu_lib):
-    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
+def _bench(args, env=None, launcher_ranks=None, port=29541):
+    """bench.py as the driver calls it (plain `python bench.py ...`: with --gpus N > 1 it starts its ranks itself), or - launcher_ranks -
+    under torch.distributed.run."""
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env or os.environ)
+
+
+def _one_line(p):
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = _json_lines(p.stdout.decode())
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "3", "--warmup", "1", "--batch-log2", "20", "--no-cpu-baseline"]
+
+
+@pytest.mark.timeout(900)
+def test_plain_gpus_2_starts_two_ranks_gloo(gpu_lib):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (child process), they share cuda:0 over gloo;
+    n_gpus is the number of ranks that joined; rank 0 re-runs both streams alone and finds the merged table (merge_check)."""
+    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    d = _one_line(_bench(["--gpus", "2"] + SMALL, env))
     assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and "cpu_baseline" not in d
+    assert d["merge_check"]["verified"] is True and len(d["table_digest"]) == 32
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_ratio_chain_gloo(gpu_lib):
-    """-y ratio on two ranks: deferred accumulation + rank-to-rank chain (dist.chain_ratio), collectives warmed up before timing."""
+def test_world_size_mismatch_is_an_error(gpu_lib):
+    """Two ranks from a launcher but --gpus 1 (or the reverse): an error, not a silent run at another size."""
     env = dict(os.environ, MM_BENCH_BACKEND="gloo")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20",
-                        "--workload", "c5"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = _json_lines(p.stdout.decode())
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and d["table_rows"] > 0
+    p = _bench(["--gpus", "1"] + SMALL, env, launcher_ranks=2, port=29551)
+    assert p.returncode != 0 and b"WORLD_SIZE=2" in p.stderr and not _json_lines(p.stdout.decode())
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("workload", ["c3", "c4", "c5"])
+def test_strong_scaling_same_digest_for_every_n(gpu_lib, workload):
+    """--scaling strong deals ONE seeded stream out over the ranks (by read name, qid mod N; -y ratio: consecutive blocks), so the
+    job's table is the same for every N: equal table_digest from 1 and 2 ranks (gloo, sharing cuda:0)."""
+    env = dict(os.environ, MM_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    args = SMALL + ["--scaling", "strong", "--workload", workload, "--legs", "resident"]
+    d1 = _one_line(_bench(["--gpus", "1"] + args, env))
+    d2 = _one_line(_bench(["--gpus", "2"] + args, env))
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d1["scaling"] == d2["scaling"] == "strong"
+    assert d1["stats"] == d2["stats"] and d1["stats"]["nHits"] == 4 * (1 << 20)
+    assert d1["table_digest"] == d2["table_digest"] and d1["table_rows"] == d2["table_rows"] > 0
+    assert d2["merge_check"]["verified"] is True
+    # (about half each; not exactly: the generator's read-name ids and NH values are correlated, ids of one parity hold the odd NH)
+    assert abs(d2["config"]["batch_alignments_per_gpu"] - (1 << 19)) < (1 << 19) * 0.1
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_strong_scaling_gloo(gpu_lib):
-    """--scaling strong: the job's K x 2^B tuples are split over the ranks instead of every rank bringing its own."""
+def test_two_ranks_under_a_launcher_ratio_chain_gloo(gpu_lib):
+    """The way the driver starts N > 1 (torch.distributed.run): -y ratio on two ranks - deferred accumulation + rank-to-rank chain
+    (dist.chain_ratio), collectives warmed up before timing - and the chain's result checked against one context in rank order."""
     env = dict(os.environ, MM_BENCH_BACKEND="gloo")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-log2", "20",
-                        "--scaling", "strong"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    d = json.loads(_json_lines(p.stdout.decode())[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["stats"]["nHits"] == 4 * (1 << 20) and d["config"]["batch_alignments_per_gpu"] == 1 << 19
+    d = _one_line(_bench(["--gpus", "2", "--workload", "c5"] + SMALL, env, launcher_ranks=2, port=29543))
+    assert d["n_gpus"] == 2 and d["stats"]["nHits"] == 2 * 4 * (1 << 20) and d["table_rows"] > 0 and d["merge_check"]["verified"] is True
 
 
 @pytest.mark.timeout(900)

@@ -58,7 +58,15 @@ def main():
     p = "profiles/pmc_latest.json"
     if os.path.exists(p):
         latest = json.load(open(p))
-    latest[wl] = {"source": f"profiles/{rnd}_{wl}_pmc.json",
+    # which kernel source the counters were collected on (tools/profile_all.sh notes it on the GPU box): bench.py hands the figure out
+    # only while that is the source it runs
+    shaf = os.path.join(base, f"{wl}_mm_device_sha.txt")
+    if os.path.exists(shaf):
+        sha = open(shaf).read().split()[0][:16]
+    else:
+        import hashlib
+        sha = hashlib.sha256(open("mmannot_amd/csrc/mm_device.hip", "rb").read()).hexdigest()[:16]
+    latest[wl] = {"source": f"profiles/{rnd}_{wl}_pmc.json", "mm_device_sha": sha,
                   "k_probe_hbm_bytes_per_launch": res.get("k_probe", {}).get("hbm_bytes_per_launch")}
     json.dump(latest, open(p, "w"), indent=1, sort_keys=True)
     for k in sorted(res):

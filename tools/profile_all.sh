@@ -9,6 +9,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
 for w in "$@"; do
+  sha256sum mmannot_amd/csrc/mm_device.hip > gpurun_out/prof/${w}_mm_device_sha.txt
   rm -rf gpurun_out/prof/${w}_trace gpurun_out/prof/${w}_fetch gpurun_out/prof/${w}_write gpurun_out/prof/${w}_l2
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/${w}_trace -- python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --legs resident > gpurun_out/prof/${w}_trace.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/${w}_fetch -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --legs resident > gpurun_out/prof/${w}_fetch.log 2>&1
