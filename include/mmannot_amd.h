@@ -191,6 +191,11 @@ int mm_get_hit_intervals(mm_ctx *ctx, uint32_t *counts, uint32_t *idx, size_t ca
  * out[1]: batches whose multi-hit records arrived already grouped by read name (non-decreasing qids, as in an aligner's
  * unsorted output) and therefore skipped the name sort. */
 int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
+/* The same two, and out[2]: tuples the pipelined probe (k_probe_fast: 32-byte slots of 4-byte records, three tuples in flight per lane)
+ * handed on to the general walk since the last mm_reset - bins with more than 7 records, reads longer than the slots' saturating fields
+ * allow or without CIGAR operations, NH values from the side list, hits that need the max-overlap / min-distance selection
+ * (mmannot.cpp:1049-1075); out[3]: bytes of the fast slot table (0: the index has none). */
+int mm_get_probe_stats(mm_ctx *ctx, uint64_t out[4]);
 
 /* Multi-GPU -y ratio.  regionCounts[set] += 1.0/nHits is a file-order double sum (mmannot.cpp:1730): ranks holding consecutive
  * blocks of the file chain it.  With mm_options.defer_ratio the batches are probed and sorted as usual but their accumulation is
@@ -220,6 +225,9 @@ size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet
  * an all_reduce of the dense count vector over RCCL instead: mmannot_amd/dist.py.) */
 int mm_partition(const mm_aln *aln, size_t n, const mm_nh_big *big, size_t n_big, int n_parts, mm_aln *const *out, size_t *out_n,
                  mm_nh_big *const *out_big, size_t big_cap, size_t *out_n_big, uint32_t *out_max_nh, uint64_t *out_qid_lo);
+/* host threads mm_partition uses (default: the cores the process may run on, at most 16; MM_PARTITION_THREADS in the environment):
+ * n >= 1 sets the number - taken as given, also for small batches - n = 0 only asks; returns the number in use. */
+int mm_partition_threads(int n);
 int mm_merge(mm_ctx *const *ctxs, int n_ctx, int strategy, uint64_t *masks, double *sums, size_t cap, size_t *n_rows,
              uint64_t stats[MM_N_STATS]);
 

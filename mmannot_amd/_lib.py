@@ -74,6 +74,7 @@ SYMBOLS = {
     "mm_get_hit_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mm_get_hit_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_get_probe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mm_set_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -82,6 +83,7 @@ SYMBOLS = {
     "mm_row_chunk": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "mm_partition": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "mm_partition_threads": (C.c_int, [C.c_int]),
     "mm_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "mm_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mm_get_phase_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -313,6 +313,12 @@ class Counter:
         check(lib().mm_get_walk_stats(self._h, a))
         return int(a[0])
 
+    def probe_stats(self) -> Dict[str, int]:
+        """tuples the pipelined probe handed on to the general walk since clear(), and the size of its slot table"""
+        a = (C.c_uint64 * 4)()
+        check(lib().mm_get_probe_stats(self._h, a))
+        return dict(walked=int(a[0]), grouped_batches=int(a[1]), passed_on=int(a[2]), fast_slot_bytes=int(a[3]))
+
     def grouped_batches(self) -> int:
         """Batches whose multi-hit records were already grouped by read name (no name sort needed)."""
         a = (C.c_uint64 * 2)()

@@ -190,6 +190,11 @@ struct ProbeParams {
   const uint2 *chrSlot;     // per chromosome {first slot, number of slots}
   const u32 *slotBits;      // one bit per slot: does it hold any record?  NULL when too few slots are empty for the test to pay
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
+  const uint4 *fslots;      // fast slots: 32 B per bin (see mm_index_create); NULL = none
+  const u32 *fbits;         // one bit per fast slot: any record (or the overflow mark)?
+  const uint2 *fchr;        // per chromosome {first fast slot, number of fast slots}
+  u32 fLmax;                // longest read the fast slots answer exactly
+  u32 fshift, freach;       // the fast slots' own bin width and reach
   u32 sshift;
   u32 reach;               // a slot also lists the intervals starting in the first `reach` bases of the next bin
   int useSlots;
@@ -208,6 +213,11 @@ __device__ __forceinline__ u32 hash64(u64 k) {
   k *= 0x9E3779B97F4A7C15ull;
   return (u32) (k >> 40);
 }
+
+// a word of the workgroup's LDS tables that other lanes may have changed: a relaxed atomic load (a `volatile` access is fenced with
+// s_waitcnt vmcnt(0) lgkmcnt(0), which drains every global load the probe has in flight)
+template <typename T>
+__device__ __forceinline__ T lds_peek(T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <u32 CAP>
 struct LdsTableT {
@@ -229,7 +239,7 @@ template <u32 CAP>
 __device__ __forceinline__ bool lds_table_add(LdsTableT<CAP> &t, u64 m, u32 inc) {
   u32 h = hash64(m) & (CAP - 1);
   for (u32 p = 0; p < LT_MAXPROBE; ++p) {
-    u64 k = *(volatile u64 *) &t.key[h];
+    u64 k = lds_peek(&t.key[h]);
     if (k == 0) {
       k = atomicCAS(&t.key[h], 0ull, m);
       if (k == 0) k = m;
@@ -247,13 +257,13 @@ template <u32 CAP>
 __device__ __forceinline__ u32 lds_cached_slot(LdsTableT<CAP> &t, const struct GlobalTable &g, u64 m) {
   u32 h = hash64(m) & (CAP - 1);
   for (u32 p = 0; p < LT_MAXPROBE; ++p) {
-    u64 k = *(volatile u64 *) &t.key[h];
+    u64 k = lds_peek(&t.key[h]);
     if (k == 0) {
       k = atomicCAS(&t.key[h], 0ull, m);
       if (k == 0) k = m;
     }
     if (k == m) {
-      u32 sl = *(volatile u32 *) &t.slot[h];
+      u32 sl = lds_peek(&t.slot[h]);
       if (sl == NO_KEY) { sl = gt_find_or_insert(g, m); t.slot[h] = sl; }
       return sl;
     }
@@ -273,7 +283,7 @@ template <u32 CAP>
 __device__ __forceinline__ u32 slot_of_set(LdsTableT<CAP> &t, const struct GlobalTable &g, u64 m) {
   if ((m & (m - 1)) == 0) {
     const int e = __ffsll((long long) m) - 1;
-    u32 sl = *(volatile u32 *) &t.singleSlot[e];
+    u32 sl = lds_peek(&t.singleSlot[e]);
     if (sl == NO_KEY) { sl = gt_find_or_insert(g, m); t.singleSlot[e] = sl; }
     return sl;
   }
@@ -435,6 +445,8 @@ __device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c
 // fast slots (4-byte bin-relative records, see mm_index_create): usable up to this bin shift - beyond it the saturating length field
 // (24 - shift - 1 bits) is shorter than a bin
 #define FS_MAX_SHIFT 11
+#define FS_MIN_SHIFT 7
+#define FS_OVERFLOW_SHARE 0.01      // bins holding more than 7 records: above this share the fast table takes half the bin width
 #define FS_OVERFLOW 0x80000000u     // header: more than 7 records - the tuple takes the 8-byte slots
 
 template <int OVL>
@@ -936,6 +948,235 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_sets(const ProbePar
     const int4 a = ld_stream(aln + i);
     if (tuple_nh((u32) a.z, i, big, nbig, err) > 1) hm[i] = probe_tuple<OVL>(P, P.useSlots != 0, chrSlot, sLine, a, walked);
   }
+}
+
+// ----------------------------------------------------------------------------- k_probe_fast (round 3)
+// The same answers as k_probe for the tuples it takes, through the 32-byte fast slots (4-byte bin-relative records, mm_index_create)
+// and a software pipeline per lane.  Why: k_probe's waves spend two thirds of their time in s_waitcnt on a chain of three dependent
+// loads per tuple (tuple -> bitmap word -> slot line [-> rest of the line]) with nothing else in flight (profiles/r02e, r03a), and a
+// dependent second access to a slot line costs as much as the first (profiles/r03a_exp_gather.txt: 0.31 -> 0.46-0.57 ms per 2^24).
+// Here one workgroup takes a tile of RS_TILE tuples and every lane keeps three tuples in flight:
+//     iteration k:  wait: slot(k) has landed in LDS, tuple(k+1) in registers
+//                   request bitmap word(k+1), tuple(k+2);  when the word is there: request slot(k+1) - the whole 32 bytes, by LDS-DMA
+//                   (global_load_lds_dwordx4: no destination registers while in flight; each lane reads back its own 32 bytes only)
+//                   test the records of slot(k) - straight-line, no further load
+// so the slot fetch of tuple k+1 (the long pole: an L2 miss) and the stream of tuple k+2 overlap the arithmetic on tuple k, and the
+// loop has no load that depends on another load of the same iteration except the bitmap word (L2).  Everything that would need one -
+// more than 7 records in the bin, a read that spans further than its slot's reach, is longer than the saturating fields allow or has
+// no CIGAR operations, the second selection pass (several elements of the winning Order line: mmannot.cpp:1049-1075) - is not done
+// here: the tuple's index goes to a list (a region per wave: no atomics) and k_probe_list walks it with k_probe's code right after.
+#define FS_LT_CAP 128u
+template <int OVL, int VAR>
+__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_fast(const ProbeParams P, const int4 *__restrict__ aln, int single, u32 qlo, size_t n,
+                                                                  u32 *__restrict__ gkey, u32 *__restrict__ gpay, u32 *__restrict__ info, GlobalTable G,
+                                                                  u64 *__restrict__ stats, u32 *__restrict__ hist, u32 nblk, u32 *__restrict__ dlist,
+                                                                  u32 *__restrict__ dlist2, u32 *__restrict__ dcnt) {
+  constexpr bool useHist = VAR == PV_GROUPS_HIST || VAR == PV_RATIO_HIST;
+  constexpr bool haveKey = VAR != PV_COUNT;
+  constexpr bool grouped_strategy = VAR == PV_GROUPS || VAR == PV_GROUPS_HIST;
+  constexpr bool ratio = VAR == PV_RATIO || VAR == PV_RATIO_HIST;
+  __shared__ LdsTableT<FS_LT_CAP> T;
+  __shared__ u32 sHist[useHist ? RS_BINS : 1];
+  __shared__ u32 sstat[8];
+  __shared__ u32 sq[3];
+  __shared__ u64 sLine[64];
+  __shared__ uint2 sChr[MM_LDS_CHR];
+  // landing zones of the loads in flight (LDS-DMA: no destination registers, and invisible to the compiler's vmcnt bookkeeping - every
+  // wait on them is written out below): lane t's slot is S[0][t], S[1][t]; its next tuple is TU[t]
+  __shared__ uint4 S[2][256];
+  __shared__ uint4 TU[256];
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < 64) sLine[t] = P.lineMask[t];
+  for (u32 c = t; c < min(P.nchr, (u32) MM_LDS_CHR); c += 256) sChr[c] = P.fchr[c];
+  lds_table_init(T);
+  if (t < 8) sstat[t] = 0;
+  if (t < 3) sq[t] = 0;
+  if (useHist) for (u32 d = t; d < RS_BINS; d += 256) sHist[d] = 0;
+  __syncthreads();
+  const bool uniqueOnly = VAR == PV_COUNT && P.strategy == MM_STRAT_UNIQUE;
+  const size_t first = (size_t) blockIdx.x * RS_TILE;
+  const size_t last = min(n, first + (size_t) RS_TILE);
+  const int nit = (int) ((last - first + 255) / 256);
+  const u32 sshift = P.fshift, soMask = (2u << sshift) - 1u;
+  const u32 ldsS = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (size_t) &S[0][t & ~63u]);   // this wave's KiB of S[0]; S[1] lies 4 KiB behind
+  const u32 ldsT = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (size_t) &TU[t & ~63u]);
+  ProbeAcc A;
+  u32 dn = 0;                                            // tuples this wave has passed on so far
+  u32 *const dl = dlist + first + (size_t) w * (RS_TILE / 4);
+
+  // stage "locate" of a tuple: which slot, may this kernel answer it, is the slot empty; requests the slot's 32 bytes and the tuple
+  // two iterations ahead.  fl: bit 0 = has a tuple, 1 = skipped by -y unique, 2 = passed on, 3 = slot requested
+  int4 a0 = make_int4(0, 0, 0, 0), a1 = a0;            // tuple it (located, its slot requested), it + 1 (loaded)
+  u32 fl0 = 0;
+  int bs0 = 0;                                           // first base of tuple it's bin
+#define MM_FAST_LOCATE(A_, I_, FL_, BS_, I2_)                                                                         \
+  {                                                                                                                  \
+    /* straight-line up to the bitmap word: a load whose use sits in another branch than the load makes the compiler wait with \
+       vmcnt(0) where the branches join - behind our requests, which that wait would then drain */                    \
+    const bool val_ = (I_) < last;                                                                                   \
+    const u32 tid1_ = TSN_TID1((A_).z);                                                                              \
+    const u32 nhf_ = ((u32) (A_).z >> 1) & MM_ALN_NH_ESCAPE;                                                         \
+    const bool known_ = val_ && tid1_ != 0 && tid1_ <= P.nchr;                                                       \
+    const uint2 cs_ = sChr[known_ ? tid1_ - 1 : 0];                                                                  \
+    const u32 nb_ = known_ ? cs_.y : 0u;                                                                             \
+    const u32 sb_ = (u32) (A_).x >> sshift, eb_ = (u32) (A_).y >> sshift, ebc_ = min(eb_, nb_ - 1);                  \
+    const bool one_ = ebc_ == sb_ || (ebc_ == sb_ + 1 && eb_ == ebc_ && (u32) (A_).y - (ebc_ << sshift) < P.freach); \
+    const bool skip_ = val_ && uniqueOnly && nhf_ != 1u;                                                             \
+    const bool esc_ = nhf_ == MM_ALN_NH_ESCAPE;        /* NH in the side list: a dependent load - not in this loop */ \
+    const bool look_ = nb_ != 0 && !skip_;                                                                           \
+    const bool elig_ = look_ && !esc_ && (A_).y >= (A_).x && sb_ < nb_ && (u32) ((A_).y - (A_).x) < P.fLmax && one_; \
+    const bool pass_ = val_ && !skip_ && (esc_ || (look_ && !elig_));                                                \
+    const u32 slot_ = elig_ ? cs_.x + sb_ : 0u;                                                                      \
+    BS_ = (int) (sb_ << sshift);                                                                                     \
+    const u32 bw_ = P.fbits[slot_ >> 5];                                                                             \
+    const bool full_ = elig_ && ((bw_ >> (slot_ & 31u)) & 1u);                                                       \
+    FL_ = (val_ ? 1u : 0u) | (skip_ ? 2u : 0u) | (pass_ ? 4u : 0u) | (full_ ? 8u : 0u);                              \
+    if (full_) {                                                                                                     \
+      const uint4 *src_ = P.fslots + (size_t) slot_ * 2, *src1_ = src_ + 1;                                          \
+      u32 keep_;                                                                                                     \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"         \
+                   "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"              \
+                   : "=&s"(keep_) : "v"(src_), "v"(src1_), "s"(ldsS), "s"(ldsS + 4096u) : "memory");                 \
+    }                                                                                                                \
+    if ((I2_) < last) {                                                                                              \
+      const int4 *src_ = aln + (I2_);                                                                                \
+      u32 keep_;                                                                                                     \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(src_), "s"(ldsT) : "memory");                                                \
+    }                                                                                                                \
+  }
+  // prologue: tuple 0 located and its slot requested, tuple 1 requested
+  if (first + t < last) a0 = ld_stream(aln + first + t);
+  MM_FAST_LOCATE(a0, first + t, fl0, bs0, first + 256 + t)
+  u32 pkey = 0, ppay = 0;
+  size_t pi = (size_t) -1;                               // outputs of the previous tuple, stored one iteration late (see below)
+  for (int it = 0; it < nit; ++it) {
+    const size_t i = first + (size_t) it * 256 + t;
+    // slot(it) and tuple(it+1) are in LDS: everything requested so far has arrived
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint4 q0 = S[0][t], q1 = S[1][t];
+    { const uint4 u = TU[t]; a1 = make_int4((int) u.x, (int) u.y, (int) u.z, (int) u.w); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next requests may land in S / TU right away)
+    // the previous tuple's outputs go out now, ahead of this iteration's requests: at the loop's wait they are the oldest and long done
+    // (stores count in vmcnt like loads, in issue order - issued last they would be what every wave waits for)
+    if (haveKey && pi != (size_t) -1) { gkey[pi] = pkey; gpay[pi] = ppay; }
+    // tuple it+1: locate, bitmap word, slot request; tuple it+2: request
+    u32 fl1; int bs1;
+    MM_FAST_LOCATE(a1, i + 256, fl1, bs1, i + 512)
+    // ---- tuple `it` against its slot
+    const bool valid = (fl0 & 1u) != 0;
+    u32 nh = ((u32) a0.z >> 1) & MM_ALN_NH_ESCAPE;
+    if (single && valid && nh > 1) { atomicCAS(G.err, 0u, (u32) ERR_SINGLE_HIT); nh = 1; }   // MM_BATCH_SINGLE_HIT was a promise
+    bool defer = (fl0 & 4u) != 0;
+    u64 mask = 0;
+    if (fl0 & 8u) {
+      if (q0.x & FS_OVERFLOW) defer = true;
+      else {
+        const int rec_strand = a0.z & 1;
+        const u32 okbit = 24u + (u32) ((P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1)));
+        const int sr = a0.x - bs0, er = a0.y - bs0;       // the read relative to its bin (sr >= 0)
+        const u32 nA = q0.x & 15u, nR = (q0.x >> 4) & 15u;
+        u64 hit = 0;
+#define MM_FAST_TEST(J, R)                                                                                       \
+  {                                                                                                              \
+    const u32 r_ = (R), pl_ = r_ & 0xFFFFFFu;                                                                    \
+    const bool act_ = (J) < nA;                                                                                  \
+    const int so_ = act_ ? 0 : (int) (pl_ & soMask);                                                             \
+    const int ie_ = act_ ? (int) pl_ : so_ + (int) (pl_ >> (sshift + 1));                                        \
+    hit |= (u64) ((u32) ((J) < nR) & span_pass<OVL>(P, so_, ie_, (r_ >> okbit) & 1u, sr, er)) << (r_ >> 26);    \
+  }
+        MM_FAST_TEST(0u, q0.y) MM_FAST_TEST(1u, q0.z) MM_FAST_TEST(2u, q0.w)
+        if (nR > 3) { MM_FAST_TEST(3u, q1.x) MM_FAST_TEST(4u, q1.y) MM_FAST_TEST(5u, q1.z) MM_FAST_TEST(6u, q1.w) }
+#undef MM_FAST_TEST
+        if (hit) {   // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
+          const u64 cand = hit & sLine[__ffsll((long long) hit) - 1];
+          // one element, or inclusion without "upstream" / "downstream" elements (every passing interval has overlap 1, distance 0: all tie)
+          if ((cand & (cand - 1)) == 0 || (OVL == MM_OVL_INCLUSION && !(cand & (P.elemUp | P.elemDown)))) mask = cand;
+          else defer = true;                               // max overlap / min distance over last writers: k_probe_list
+        }
+      }
+    }
+    const bool processed = valid && !(fl0 & 2u) && !defer;
+    {                                                      // pass the tuple on: this wave's region of the list, no atomics
+      const u64 dm = __ballot(defer);
+      if (dm) {
+        if (defer) dl[dn + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = (u32) i;
+        dn += (u32) __popcll(dm);
+      }
+    }
+    u32 key, pay;
+    tuple_tail(grouped_strategy, ratio, false, useHist ? HIST_LDS : HIST_NONE, T, sHist, hist, nblk, G, qlo, lane, i, a0, nh, processed, mask, A, key, pay);
+    pi = (valid && !defer) ? i : (size_t) -1;              // (k_probe_list writes the outputs of the tuples it is handed)
+    pkey = key; ppay = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
+    a0 = a1; fl0 = fl1; bs0 = bs1;
+  }
+#undef MM_FAST_LOCATE
+  if (haveKey && pi != (size_t) -1) { gkey[pi] = pkey; gpay[pi] = ppay; }
+  // the four waves' regions -> one list for the whole batch (one atomic per workgroup), so that k_probe_list runs on full wavefronts
+  __shared__ u32 wcnt[4], wbase[4];
+  if (lane == 0) wcnt[w] = dn;
+  __syncthreads();                                         // (also: the waves' writes to their regions are done)
+  if (t == 0) {
+    const u32 tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    u32 b = tot ? atomicAdd(dcnt, tot) : 0u;
+    for (u32 q = 0; q < 4; ++q) { wbase[q] = b; b += wcnt[q]; }
+  }
+  __syncthreads();
+  for (u32 j = lane; j < dn; j += 64) dlist2[wbase[w] + j] = __builtin_nontemporal_load(dl + j);
+  if (useHist) for (u32 d = t; d < RS_BINS; d += 256) if (sHist[d]) hist[(size_t) d * nblk + blockIdx.x] = sHist[d];
+  probe_finish(grouped_strategy, ratio, haveKey, A, sstat, sq, T, G, stats, info);
+}
+
+// The tuples k_probe_fast passed on (dlist[0 .. *dcnt)), through k_probe's walk (8-byte slots, full index, second selection pass) and
+// the same tail.  The partition histogram of the batch (hist != NULL: k_probe_fast has stored its tiles' counts, the host zeroed the
+// rest) gets these tuples' digits by atomics.  The list is a few per cent of a batch, heavy tuples mostly (bins with many records), and a
+// chain of dependent loads each: what matters is that all of them are in flight at once - one tuple per lane, as many workgroups as the
+// list needs (the others leave at once).
+template <int OVL>
+__global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_list(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
+                                                                  int single, u32 qlo, u32 *__restrict__ gkey, u32 *__restrict__ gpay, u32 *__restrict__ info,
+                                                                  GlobalTable G, u64 *__restrict__ stats, u32 *__restrict__ hist, u32 nblk,
+                                                                  const u32 *__restrict__ dlist, const u32 *__restrict__ dcnt, u64 *__restrict__ walkstat) {
+  __shared__ LdsTable T;
+  __shared__ u32 sstat[8];
+  __shared__ u32 sq[3];
+  __shared__ u64 sLine[64];
+  __shared__ uint2 sChr[MM_LDS_CHR];
+  const u32 total = *dcnt;
+  if ((size_t) blockIdx.x * 256 >= total) return;          // (uniform)
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&walkstat[2], (u64) total);   // profiling aid: tuples passed on (mm_get_probe_stats)
+  if (threadIdx.x < 64) sLine[threadIdx.x] = P.lineMask[threadIdx.x];
+  for (u32 c = threadIdx.x; c < min(P.nchr, (u32) MM_LDS_CHR); c += blockDim.x) sChr[c] = P.chrSlot[c];
+  const uint2 *chrSlot = P.nchr <= (u32) MM_LDS_CHR ? sChr : P.chrSlot;
+  lds_table_init(T);
+  if (threadIdx.x < 8) sstat[threadIdx.x] = 0;
+  if (threadIdx.x < 3) sq[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  const bool grouped_strategy = P.strategy == MM_STRAT_DEFAULT, ratio = P.strategy == MM_STRAT_RATIO, uniqueOnly = P.strategy == MM_STRAT_UNIQUE;
+  const bool haveKey = gkey != nullptr;
+  ProbeAcc A;
+  u32 walked = 0;
+  for (size_t base = (size_t) blockIdx.x * 256; base < total; base += (size_t) gridDim.x * 256) {
+    const size_t j = base + threadIdx.x;
+    const bool valid = j < total;
+    size_t i = 0;
+    int4 a = make_int4(0, 0, 0, 0);
+    u32 nh = 1;
+    if (valid) {
+      i = dlist[j];
+      a = aln[i];
+      nh = tuple_nh((u32) a.z, i, big, nbig, G.err);
+      if (single && nh > 1) { atomicCAS(G.err, 0u, (u32) ERR_SINGLE_HIT); nh = 1; }
+    }
+    const bool processed = valid && !(uniqueOnly && nh != 1);
+    u64 mask = 0;
+    if (processed) mask = probe_tuple<OVL>(P, true, chrSlot, sLine, a, walked);
+    u32 key, pay;
+    tuple_tail(grouped_strategy, ratio, false, hist ? HIST_GLOBAL : HIST_NONE, T, (u32 *) nullptr, hist, nblk, G, qlo, lane, i, a, nh, processed, mask, A, key, pay);
+    if (valid && haveKey) { gkey[i] = key; gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16)); }
+  }
+  probe_finish(grouped_strategy, ratio, haveKey, A, sstat, sq, T, G, stats, info);
 }
 
 // ----------------------------------------------------------------------------- grouping pipeline: tiles of (key, payload) pairs
@@ -2065,6 +2306,10 @@ struct mm_index {
   // bin width does not allow the encoding (see FS_* below)
   uint4 *d_fslots = nullptr;
   u32 *d_fbits = nullptr;
+  uint2 *d_fchr = nullptr; // per chromosome {first fast slot, number of fast slots}
+  int fshift = 0;          // log2 of the fast slots' bin width (may be one less than sshift)
+  u32 freach = 0;
+  size_t n_fslots = 0;
   u32 fLmax = 0;           // longest read the fast slots answer exactly
   u64 elemF = 0, elemR = 0, elemUp = 0, elemDown = 0;
   u64 lineMask[64];
@@ -2096,6 +2341,10 @@ struct mm_ctx {
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
+  u32 *d_dlist = nullptr, *d_dcnt = nullptr;   // tuples k_probe_fast passes on to k_probe_list: one region per wave of a tile, and the regions' lengths
+  // A/B switches of the environment, read once (mm_ctx_create): MMANNOT_AMD_NO_FUSED_HIST, MMANNOT_AMD_GENERAL_PROBE, MMANNOT_AMD_FULL_INDEX_ONLY,
+  // MMANNOT_AMD_NO_FAST (the round-2 walk instead of the pipelined one)
+  bool env_no_fused_hist = false, env_general_probe = false, env_full_index_only = false, env_no_fast = false;
   u64 *d_tileTot = nullptr;
   int *d_tileK = nullptr;
   size_t last_n = 0;
@@ -2243,6 +2492,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   std::vector<int> longEnd;
   std::vector<uint4> fslots;
   std::vector<u32> fbits;
+  std::vector<uint2> fchr;
   {
     // Bin width.  Bins holding more than 7 records leave the one-sector fast path (their list continues in `flat`),
     // so the widest bin width is chosen whose share of such bins stays below 2 %, among the widths whose table (64 B
@@ -2333,51 +2583,6 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       const u32 n = std::min<u32>(total, 7u);
       for (u32 r = 0; r < n; ++r) { w[2 + 2 * r] = flat[off[k] + r].x; w[3 + 2 * r] = flat[off[k] + r].y; }
     }
-    // ---- fast slots (k_probe_fast): per bin 32 bytes = header + up to 7 records of 4 bytes, relative to the bin's first base.
-    //   record = element:6 << 26 | ok('+' read):1 << 25 | ok('-' read):1 << 24 | payload:24
-    //   payload of an interval open at the bin's left edge (the first nA records) = min(end - binStart, 2^24 - 1);
-    //   payload of one starting in the bin, or in the `reach` bases behind it = (start - binStart) : sshift + 1 bits | min(end - start, FS_LSAT) above.
-    // A saturated field says "at least": the kernel sends only reads to these slots that end before any saturated end could matter
-    // (read length <= fLmax = FS_LSAT - W, start inside the chromosome's bins), so every test stays exact.  Intervals that end before the
-    // bin starts cannot pass for a read with end >= start and are left out.  More than 7 records: the overflow bit (the tuple then takes
-    // the 8-byte slots above, as do reads that are too long, span more bins, have no CIGAR operations, or need the second selection pass).
-    if (sh <= FS_MAX_SHIFT) {
-      const u32 lenBits = 24u - (u32) (sh + 1), LSAT = (1u << lenBits) - 1u;
-      ix->fLmax = LSAT - W;
-      fslots.assign(ns * 2, make_uint4(0u, 0u, 0u, 0u));
-      fbits.assign((ns + 31) / 32 + 1, 0u);
-      for (int c = 0; c < n_chromosomes; ++c) {
-        if (!seen[c]) continue;
-        for (u32 b = 0; b < sN[c]; ++b) {
-          const u64 k = (u64) sBase[c] + b;
-          const int64_t binStart = (int64_t) b << sh;
-          u32 rec[7], n = 0, nA = 0;
-          bool ovf = false;
-          const u32 total = nAct[k] + nIv[k] + nOvh[k];
-          for (u32 r = 0; r < total; ++r) {
-            const uint2 fr = flat[off[k] + r];
-            const int64_t is = (int64_t) fr.x;
-            const u32 flen = fr.y & REC_LEN_MASK;
-            const int64_t ie = (fr.y & REC_LONG) ? (int64_t) longEnd[flen] : is + (int64_t) flen;
-            const u32 head = (REC_TYPE(fr.y) << 26) | (((fr.y >> (REC_OKBIT + 1)) & 1u) << 25) | (((fr.y >> REC_OKBIT) & 1u) << 24);
-            u32 payload;
-            if (r < nAct[k]) {
-              if (ie < binStart) continue;
-              payload = (u32) std::min<int64_t>(ie - binStart, 0xFFFFFF);
-            } else {
-              payload = (u32) (is - binStart) | ((u32) std::min<int64_t>(ie - is, (int64_t) LSAT) << (sh + 1));
-            }
-            if (n == 7) { ovf = true; break; }
-            if (r < nAct[k]) ++nA;
-            rec[n++] = head | payload;
-          }
-          u32 *w = (u32 *) &fslots[k * 2];
-          if (ovf) { w[0] = FS_OVERFLOW; n = 0; }
-          else { w[0] = nA | (n << 4); for (u32 r = 0; r < n; ++r) w[1 + r] = rec[r]; }
-          if (ovf || n) fbits[k >> 5] |= 1u << (k & 31);
-        }
-      }
-    }
     u64 nonEmpty = 0;
     for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k] + nOvh[k]) ? 1 : 0;
     if ((double) (ns - nonEmpty) < 0.33 * (double) ns) slotBits.clear();
@@ -2385,6 +2590,97 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
     // SLOWER (0.354 -> 0.394 ms per 2^24 tuples): the rank arithmetic sits on the dependent chain and costs the 64-VGPR budget a spill.)
     ix->n_slots = ns; ix->n_flat = off[ns]; ix->n_slotBits = slotBits.size();
+  }
+  // ---- fast slots (k_probe_fast): per bin 32 bytes = header + up to 7 records of 4 bytes, relative to the bin's first base.
+  //   header = nA | n << 4 (the first nA of the n records are intervals open at the bin's left edge), or FS_OVERFLOW
+  //   record = element:6 << 26 | ok('+' read):1 << 25 | ok('-' read):1 << 24 | payload:24
+  //   payload of an interval open at the bin's left edge = min(end - binStart, 2^24 - 1);
+  //   payload of one starting in the bin, or in the `reach` bases behind it = (start - binStart) : shift + 1 bits | min(end - start, LSAT) above.
+  // A saturated field says "at least": the kernel sends only reads to these slots that end before any saturated end could matter
+  // (read length <= fLmax = LSAT - W, start inside the chromosome's bins), so every test stays exact.  Intervals that end before the
+  // bin starts cannot pass for a read with end >= start and are left out; inverted zero-size intervals too (as above).  More than 7
+  // records: the overflow mark (the tuple then takes the 8-byte slots above, as do reads that are too long, span more than the slot's
+  // reach, have no CIGAR operations, or need the second selection pass).  The bin width is this table's own: half the width of the
+  // 8-byte slots' where that cuts the share of overflowing bins below FS_OVERFLOW_SHARE (4-byte records: the table is no larger for
+  // it), never below 128 bases (a read has to fit a bin and its reach), at most 256 MB.
+  {
+    auto count_fast = [&](int sh, std::vector<u32> &fBase, std::vector<u32> &fN, std::vector<u32> &cA, std::vector<u32> &cI, std::vector<u32> &cO) -> u64 {
+      const u32 W = 1u << sh, reach = std::min<u32>(W, 256u);
+      fBase.assign(n_chromosomes, 0); fN.assign(n_chromosomes, 0);
+      u64 ns = 0;
+      for (int c = 0; c < n_chromosomes; ++c) if (seen[c]) { fN[c] = (u32) (maxEnd[c] >> sh) + 1; fBase[c] = (u32) ns; ns += fN[c]; }
+      cA.assign(ns + 1, 0); cI.assign(ns, 0); cO.assign(ns, 0);
+      std::vector<int32_t> diff(ns + 2, 0);
+      for (size_t i = 0; i < n_iv; ++i) {
+        if (end[i] < start[i]) continue;
+        const int c = chr[i];
+        const u32 bs = (u32) start[i] >> sh;
+        ++cI[fBase[c] + bs];
+        if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) ++cO[fBase[c] + bs - 1];
+        // open at the left edge of bins bs+1 .. (end >> sh): the bin that starts at end + 1 would only see it end before its first base
+        const u32 b1 = std::min<u32>((u32) end[i] >> sh, fN[c] - 1);
+        if (b1 > bs) { ++diff[fBase[c] + bs + 1]; --diff[fBase[c] + b1 + 1]; }
+      }
+      int32_t run = 0;
+      for (u64 k = 0; k < ns; ++k) { run += diff[k]; cA[k] = (u32) run; }
+      return ns;
+    };
+    std::vector<u32> fBase, fN, cA, cI, cO;
+    int fsh = -1;
+    u64 fns = 0;
+    const char *forced = getenv("MMANNOT_AMD_FAST_SHIFT");       // (A/B measurements)
+    for (int sh = std::min(ix->sshift, FS_MAX_SHIFT); sh >= FS_MIN_SHIFT; --sh) {
+      if (forced && atoi(forced) >= FS_MIN_SHIFT && atoi(forced) <= FS_MAX_SHIFT) sh = atoi(forced);
+      const u64 ns = count_fast(sh, fBase, fN, cA, cI, cO);
+      if (ns * 32ull > (256ull << 20) && fsh >= 0) break;       // (would be too large: keep the wider one)
+      fsh = sh; fns = ns;
+      u64 over = 0;
+      for (u64 k = 0; k < ns; ++k) over += (cA[k] + cI[k] + cO[k] > 7) ? 1 : 0;
+      if (forced || sh < ix->sshift || (double) over <= FS_OVERFLOW_SHARE * (double) ns) break;   // at most one halving
+    }
+    if (fsh >= 0 && fns * 32ull <= (1024ull << 20)) {
+      const u64 ns = count_fast(fsh, fBase, fN, cA, cI, cO);   // (the loop may have ended on a wider table than it counted last)
+      const int sh = fsh;
+      const u32 W = 1u << sh, reach = std::min<u32>(W, 256u);
+      const u32 lenBits = 24u - (u32) (sh + 1), LSAT = (1u << lenBits) - 1u;
+      ix->fshift = sh; ix->freach = reach; ix->fLmax = LSAT - W; ix->n_fslots = ns;
+      fslots.assign(ns * 2, make_uint4(0u, 0u, 0u, 0u));
+      fbits.assign((ns + 31) / 32 + 1, 0u);
+      fchr.assign(n_chromosomes, make_uint2(0u, 0u));
+      for (int c = 0; c < n_chromosomes; ++c) if (seen[c]) fchr[c] = make_uint2(fBase[c], fN[c]);
+      // headers, then the records through per-bin cursors: open ones first, then those starting in the bin, then the reach - each in index order
+      std::vector<unsigned char> curA(ns, 0), curI(ns, 0), curO(ns, 0);
+      for (u64 k = 0; k < ns; ++k) {
+        const u32 tot = cA[k] + cI[k] + cO[k];
+        u32 *w = (u32 *) &fslots[k * 2];
+        if (tot > 7) w[0] = FS_OVERFLOW;
+        else { w[0] = cA[k] | (tot << 4); curI[k] = (unsigned char) cA[k]; curO[k] = (unsigned char) (cA[k] + cI[k]); }
+        if (tot) fbits[k >> 5] |= 1u << (k & 31);
+      }
+      for (size_t i = 0; i < n_iv; ++i) {
+        if (end[i] < start[i]) continue;
+        const int c = chr[i];
+        const u32 t = type[i];
+        const bool ivF = strand[i] == MM_STRAND_F;
+        const bool eF = (ix->elemF >> t) & 1, eR = (ix->elemR >> t) & 1;
+        const bool okPlus = !(eF | eR) || (eF ? ivF : !ivF), okMinus = !(eF | eR) || (eF ? !ivF : ivF);
+        const u32 head = (t << 26) | ((okPlus ? 1u : 0u) << 25) | ((okMinus ? 1u : 0u) << 24);
+        const u32 bs = (u32) start[i] >> sh;
+        const int64_t len = (int64_t) end[i] - (int64_t) start[i];
+        const u32 lenf = (u32) std::min<int64_t>(len, (int64_t) LSAT) << (sh + 1);
+        auto put = [&](u64 k, unsigned char &cur, u32 rec) {
+          u32 *w = (u32 *) &fslots[k * 2];
+          if (w[0] != FS_OVERFLOW) w[1 + cur++] = rec;
+        };
+        { const u64 k = (u64) fBase[c] + bs; put(k, curI[k], head | lenf | ((u32) start[i] - (bs << sh))); }
+        if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) { const u64 k = (u64) fBase[c] + bs - 1; put(k, curO[k], head | lenf | ((u32) start[i] - ((bs - 1) << sh))); }
+        const u32 b1 = std::min<u32>((u32) end[i] >> sh, fN[c] - 1);
+        for (u32 b = bs + 1; b <= b1; ++b) {
+          const u64 k = (u64) fBase[c] + b;
+          put(k, curA[k], head | (u32) std::min<int64_t>((int64_t) end[i] - ((int64_t) b << sh), 0xFFFFFF));
+        }
+      }
+    }
   }
   std::vector<uint4> chrInfo(n_chromosomes);
   for (int c = 0; c < n_chromosomes; ++c) chrInfo[c] = make_uint4(binBase[c], nBins[c], ivEnd[c], 0u);
@@ -2406,7 +2702,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       (e = up((void **) &ix->d_chrSlot, chrSlot.data(), (size_t) n_chromosomes * sizeof(uint2))) != hipSuccess ||
       (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess ||
       (!fslots.empty() && ((e = up((void **) &ix->d_fslots, fslots.data(), fslots.size() * sizeof(uint4))) != hipSuccess ||
-                           (e = up((void **) &ix->d_fbits, fbits.data(), fbits.size() * sizeof(u32))) != hipSuccess))) {
+                           (e = up((void **) &ix->d_fbits, fbits.data(), fbits.size() * sizeof(u32))) != hipSuccess ||
+                           (e = up((void **) &ix->d_fchr, fchr.data(), fchr.size() * sizeof(uint2))) != hipSuccess))) {
     mm_index_destroy(ix);
     return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
   }
@@ -2418,7 +2715,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
-  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits);
+  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fchr);
   delete ix;
 }
 
@@ -2436,7 +2733,8 @@ static void ctx_free_batch(mm_ctx *c) {
   (void) hipFree(c->d_hm); (void) hipFree(c->d_gkey); (void) hipFree(c->d_gpay);
   (void) hipFree(c->d_kA); (void) hipFree(c->d_kB);
   (void) hipFree(c->d_hist); (void) hipFree(c->d_tileTot); (void) hipFree(c->d_tileK);
-  c->d_tileTot = nullptr; c->d_tileK = nullptr;
+  (void) hipFree(c->d_dlist); (void) hipFree(c->d_dcnt);
+  c->d_tileTot = nullptr; c->d_tileK = nullptr; c->d_dlist = nullptr; c->d_dcnt = nullptr;
   c->d_aln = nullptr; c->d_hm = nullptr; c->d_gkey = nullptr; c->d_gpay = nullptr;
   c->d_kA = c->d_vA = c->d_kB = c->d_vB = nullptr; c->d_hist = nullptr;
   c->cap = 0;
@@ -2455,12 +2753,17 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   if (rc) return rc;
   mm_ctx *c = new mm_ctx();
   c->ix = ix; c->opt = *opt;
+  {
+    auto on = [](const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; };
+    c->env_no_fused_hist = on("MMANNOT_AMD_NO_FUSED_HIST"); c->env_general_probe = on("MMANNOT_AMD_GENERAL_PROBE");
+    c->env_full_index_only = on("MMANNOT_AMD_FULL_INDEX_ONLY"); c->env_no_fast = on("MMANNOT_AMD_NO_FAST");
+  }
   if (stream) c->stream = (hipStream_t) stream;
   else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
   HIPCHK(hipMalloc((void **) &c->G.key, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.cnt, GT_CAP * 8));
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   c->G.nearProbes = c->opt.strategy == MM_STRAT_RATIO ? GT_NEAR_PROBES : 0u;
-  HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 2 * sizeof(u64)));
+  HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 4 * sizeof(u64)));
   HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 2) * 4));   // + the scan's "workgroups done" counter
   HIPCHK(hipMemset(c->d_rowTot, 0, (RS_ROW_COUNT + 2) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
   HIPCHK(hipMalloc((void **) &c->d_seg, 2 * GT_CAP * 4));
@@ -2501,7 +2804,7 @@ extern "C" int mm_reset(mm_ctx *c) {
   HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipMemsetAsync(c->G.key, 0, GT_CAP * 8, c->stream)); HIPCHK(hipMemsetAsync(c->G.cnt, 0, GT_CAP * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->G.sum, 0, GT_CAP * 8, c->stream)); HIPCHK(hipMemsetAsync(c->G.err, 0, 4, c->stream));
-  HIPCHK(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(u64), c->stream)); HIPCHK(hipMemsetAsync(c->d_walk, 0, 2 * sizeof(u64), c->stream));
+  HIPCHK(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(u64), c->stream)); HIPCHK(hipMemsetAsync(c->d_walk, 0, 4 * sizeof(u64), c->stream));
   if (c->qcap) {
     HIPCHK(hipMemsetAsync(c->d_grpRem, 0, c->qcap * 4, c->stream)); HIPCHK(hipMemsetAsync(c->d_grpU, 0, c->qcap * 8, c->stream));
   }
@@ -2524,6 +2827,7 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     HIPCHK(hipMalloc((void **) &c->d_kA, cap * 8)); c->d_vA = c->d_kA + cap;
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 8)); c->d_vB = c->d_kB + cap;
     HIPCHK(hipMalloc((void **) &c->d_hist, (size_t) RS_ROWS * nblk * 4));
+    HIPCHK(hipMalloc((void **) &c->d_dlist, 2 * nblk * (size_t) RS_TILE * 4)); HIPCHK(hipMalloc((void **) &c->d_dcnt, 16));
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
@@ -2563,8 +2867,9 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   const mm_index *ix = c->ix;
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
+  P.fslots = ix->d_fslots; P.fbits = ix->d_fbits; P.fchr = ix->d_fchr; P.fLmax = ix->fLmax; P.fshift = (u32) ix->fshift; P.freach = ix->freach;
   P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
-  P.useSlots = getenv("MMANNOT_AMD_FULL_INDEX_ONLY") ? 0 : 1;
+  P.useSlots = c->env_full_index_only ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
   P.overlapMode = c->opt.overlap_mode; P.overlapValue = c->opt.overlap_value;
@@ -2734,7 +3039,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   const int n_passes = dflt ? leaf_layout(span_bits).passes : 2;
   const bool force_leaf = dflt && need_groups && n_passes == 1;
   // k_probe also counts the first sort pass's digits per tile: buckets of the leaf layout, or (-y ratio) the table slots of a one-pass sort
-  const bool fuse_hist = (force_leaf || ratio) && !getenv("MMANNOT_AMD_NO_FUSED_HIST");   // (the environment switch is for A/B measurements)
+  const bool fuse_hist = (force_leaf || ratio) && !c->env_no_fused_hist;   // (the environment switch is for A/B measurements)
   if (fuse_hist) HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t) RS_BINS * nblk * sizeof(u32), c->stream));   // k_probe stores the non-zero counts only
   if (need_groups) hipLaunchKernelGGL(k_set_info, dim3(1), dim3(64), 0, c->stream, c->d_M, force_leaf ? ~(u32) qid_lo : 0u, force_leaf ? 1u : 0u);
   {
@@ -2742,8 +3047,37 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   // the instance that takes this launch's constants for granted, or the general one (side outputs, -y random, an index without slots,
   // more chromosomes than the LDS table holds; MMANNOT_AMD_GENERAL_PROBE=1 forces it for A/B measurements and tests)
   int var = PV_GENERAL;
-  if (P.useSlots && P.nchr <= (u32) MM_LDS_CHR && !P.keep && P.strategy != MM_STRAT_RANDOM && !getenv("MMANNOT_AMD_GENERAL_PROBE"))
+  if (P.useSlots && P.nchr <= (u32) MM_LDS_CHR && !P.keep && P.strategy != MM_STRAT_RANDOM && !c->env_general_probe)
     var = ratio ? (fuse_hist ? PV_RATIO_HIST : PV_RATIO) : ((dflt && need_groups) ? (fuse_hist ? PV_GROUPS_HIST : PV_GROUPS) : PV_COUNT);
+  // the pipelined walk over the fast slots (k_probe_fast) + the list of what it passes on (k_probe_list), where the index has them
+  const bool fast = var != PV_GENERAL && P.fslots != nullptr && !c->env_no_fast;
+  if (fast) {
+    u32 *const dlist2 = c->d_dlist + (size_t) nblk * RS_TILE;        // the compacted list (the first half: the waves' regions)
+    HIPCHK(hipMemsetAsync(c->d_dcnt, 0, 4, c->stream));
+#define MM_LAUNCH_FAST(OVL, VAR)                                                                                                     \
+  hipLaunchKernelGGL((k_probe_fast<OVL, VAR>), dim3(nblk), dim3(256), 0, c->stream, P, d_aln, single ? 1 : 0,                         \
+                     (u32) qid_lo, n, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk, c->d_dlist, dlist2, c->d_dcnt)
+#define MM_LAUNCH_FAST_VAR(OVL)                                       \
+  switch (var) {                                                      \
+    case PV_COUNT: MM_LAUNCH_FAST(OVL, PV_COUNT); break;              \
+    case PV_GROUPS_HIST: MM_LAUNCH_FAST(OVL, PV_GROUPS_HIST); break;  \
+    case PV_GROUPS: MM_LAUNCH_FAST(OVL, PV_GROUPS); break;            \
+    case PV_RATIO: MM_LAUNCH_FAST(OVL, PV_RATIO); break;              \
+    default: MM_LAUNCH_FAST(OVL, PV_RATIO_HIST);                      \
+  }
+#define MM_LAUNCH_LIST(OVL)                                                                                                          \
+  hipLaunchKernelGGL((k_probe_list<OVL>), dim3(std::min<u32>(2048u, (u32) ((n + 255) / 256))), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, \
+                     single ? 1 : 0, (u32) qid_lo, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk, \
+                     (const u32 *) dlist2, (const u32 *) c->d_dcnt, c->d_walk)
+    switch (c->opt.overlap_mode) {
+      case MM_OVL_INCLUSION: MM_LAUNCH_FAST_VAR(MM_OVL_INCLUSION) MM_LAUNCH_LIST(MM_OVL_INCLUSION); break;
+      case MM_OVL_PC: MM_LAUNCH_FAST_VAR(MM_OVL_PC) MM_LAUNCH_LIST(MM_OVL_PC); break;
+      default: MM_LAUNCH_FAST_VAR(MM_OVL_NT) MM_LAUNCH_LIST(MM_OVL_NT);
+    }
+#undef MM_LAUNCH_LIST
+#undef MM_LAUNCH_FAST_VAR
+#undef MM_LAUNCH_FAST
+  } else {
 #define MM_LAUNCH_PROBE(OVL, VAR)                                                                                                  \
   hipLaunchKernelGGL((k_probe<OVL, VAR>), dim3(fuse_hist ? nblk : grid), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big,    \
                      single ? 1 : 0, (u32) qid_lo, n, hm, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, c->d_walk,                   \
@@ -2761,6 +3095,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
     case MM_OVL_INCLUSION: MM_LAUNCH_PROBE_VAR(MM_OVL_INCLUSION) break;
     case MM_OVL_PC: MM_LAUNCH_PROBE_VAR(MM_OVL_PC) break;
     default: MM_LAUNCH_PROBE_VAR(MM_OVL_NT)
+  }
   }
 #undef MM_LAUNCH_PROBE_VAR
 #undef MM_LAUNCH_PROBE
@@ -3034,6 +3369,15 @@ extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
   HIPCHK(hipSetDevice(c->ix->device));
   HIPCHK(hipMemcpyAsync(out, c->d_walk, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+extern "C" int mm_get_probe_stats(mm_ctx *c, uint64_t out[4]) {
+  if (!c || !out) return fail(MM_ERR_ARG, "mm_get_probe_stats: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipMemcpyAsync(out, c->d_walk, 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  out[3] = c->ix->d_fslots ? (uint64_t) c->ix->n_fslots * 32ull : 0;
   return MM_OK;
 }
 

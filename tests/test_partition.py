@@ -21,12 +21,16 @@ def _partition(api, lib, aln, big, n_parts, big_cap=1 << 12):
     return [(outs[p][:out_n[p]], bigs[p][:out_nb[p]], int(out_mx[p]), int(out_lo[p])) for p in range(n_parts)]
 
 
-@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
-def test_partition_is_stable_and_renumbers(n_parts):
+@pytest.mark.parametrize("threads", [1, 5, 16])
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8, 11])
+def test_partition_is_stable_and_renumbers(n_parts, threads):
+    """(threads: the batch is cut into per-thread slices, counted, then scattered behind per-part prefix offsets - the result must not
+    depend on the number of threads; 11 parts: the division by a run-time value)"""
     import mmannot_amd.api as api
     from mmannot_amd._lib import lib
+    assert lib().mm_partition_threads(threads) == threads
     rng = np.random.default_rng(5)
-    n = 20000
+    n = 20003
     qid = rng.integers(0, 3000, n)
     nh = rng.integers(0, 9, n).astype(np.uint64)
     nh[rng.integers(0, n, 40)] = rng.integers(2047, 1 << 32, 40)          # some NH beyond the tuple's field
