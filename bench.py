@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--scatter-log2", type=int, default=-1, help="informational: window over which a read's hits are spread (0 = hits adjacent, "
                     "an aligner's own output order; default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--annotation-scale", type=float, default=0.0, help="scale sensitivity: multiply the workload's gene counts by this instead of its own "
+                    "factor (c3: 1.5 -> 1.27 M intervals; 3.5 -> ~3 M, BASELINE.json's '~3M features')")
+    ap.add_argument("--scaffolds", type=int, default=0, help="scale sensitivity: that many 60-kb scaffolds behind the chromosomes (> 256 reference names)")
     ap.add_argument("--legs", default="both", choices=("both", "host", "resident"), help="profiling aid: run only one leg (the JSON line of record needs both)")
     ap.add_argument("--tuple-bytes", type=int, default=16, choices=(16, 12),
                     help="bytes per tuple on the link in the from-host leg that gives `value`: 16 = mm_aln (SURVEY.md 8d, the metric of record); "
@@ -132,7 +135,12 @@ def main():
         wl["scatter"] = args.scatter_log2
         wl["name"] += f" [hits of a read spread over 2^{args.scatter_log2} tuples]"
     want_cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
-    an = synth.synth_annotation(wl["shape"], seed=args.seed, scale=wl["scale"], keep_genes=want_cpu)
+    if args.annotation_scale > 0:
+        wl["scale"] = args.annotation_scale
+        wl["name"] += f" [annotation scale {args.annotation_scale:g}]"
+    if args.scaffolds:
+        wl["name"] += f" [+ {args.scaffolds} scaffolds]"
+    an = synth.synth_annotation(wl["shape"], seed=args.seed, scale=wl["scale"], keep_genes=want_cpu, scaffolds=args.scaffolds)
     read_len, nh_max, scatter, pair, strategy, wname = wl["read_len"], wl["nh_max"], wl["scatter"], wl["pair"], wl["strategy"], wl["name"]
     cfg = mm.Config.from_json(an.config)
     index = mm.IntervalIndex(cfg, an.chr, an.start, an.end, an.type, an.strand, an.n_chromosomes, device=local_rank, bin_shift=args.bin_shift)
@@ -219,6 +227,8 @@ def main():
         return qbound_of[step]
     if nh_max > 1 and strategy == "default":
         ctr.reserve(qb)         # the per-read-name state is sized once, before any timing (a decoder that knows the number of reads)
+    if strategy == "ratio" and multi:
+        ctr.ratio_reserve(nb, max(sizes))      # buffers of the parked batches: allocated once, before any timing
 
     _pinned = {}
 
@@ -279,7 +289,8 @@ def main():
         ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
         stats = ctr.stats()
         if strategy == "ratio" and multi:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
-            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "1")))
+            # (row chunks pipeline the chain; they pay when the hops stay on the devices - RCCL - and cost more than they hide through the host)
+            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "8" if comm_dev.type == "cuda" else "1")))
         else:
             masks, sums = ctr.getCounts()
             masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
@@ -368,6 +379,10 @@ def main():
         }
         if merge_check is not None:
             out["merge_check"] = merge_check
+        if strategy == "ratio" and multi and getattr(chain_ratio, "last_hop_ms", None):
+            hm = chain_ratio.last_hop_ms
+            out["ratio_chain"] = {"chunks": len(hm), "hop_ms_rank0": hm, "note": "rank 0, last leg: per row chunk, replay of this rank's parked batches + "
+                                  "hand-over of the table to the next rank, device to device (no host hop)"}
         if res_host is not None:
             h_ms, h_n = res_host[1]["h2d"]
             avg_copy_s = h_ms / max(1, h_n) / 1e3

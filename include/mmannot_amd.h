@@ -210,6 +210,21 @@ int mm_ratio_resolve_n(mm_ctx *ctx, size_t max_runs);   /* replays only the firs
 int mm_ratio_resolve_chunk(mm_ctx *ctx, uint32_t chunk, uint32_t n_chunks);
 uint32_t mm_row_chunk(uint64_t mask, uint32_t n_chunks);
 size_t mm_ratio_pending(const mm_ctx *ctx);            /* parked batches not yet replayed */
+/* The same chain without a host hop (round 3): the whole table travels device to device - MM_TABLE_SLOTS element sets and the bit
+ * patterns of their sums, empty slots with set 0 - and every call is asynchronous on the context's stream.
+ *   mm_table_export_device: the context's table -> d_keys[MM_TABLE_SLOTS], d_sums[MM_TABLE_SLOTS] (device memory);
+ *   mm_table_import_device: n entries (device memory; set 0 = none) seed the context's rows - with n_chunks > 1 only the rows of `chunk`;
+ *   mm_ratio_replay: parked batches [first, first + count) for the rows of one chunk, nothing released, no synchronisation;
+ *   mm_ratio_release: synchronises, gives the parked batches' buffers back to the context's pool, reports errors;
+ *   mm_ratio_reserve: buffers for n_runs parked batches of up to batch_capacity tuples now (else they are allocated when first needed);
+ *   mm_ratio_handoff: src's table -> dst's rows of one chunk, across devices of one process (peer copy), stream-ordered on both sides. */
+#define MM_TABLE_SLOTS 65536
+int mm_table_export_device(mm_ctx *ctx, uint64_t *d_keys, double *d_sums);
+int mm_table_import_device(mm_ctx *ctx, const uint64_t *d_keys, const double *d_sums, size_t n, uint32_t chunk, uint32_t n_chunks);
+int mm_ratio_replay(mm_ctx *ctx, size_t first, size_t count, uint32_t chunk, uint32_t n_chunks);
+int mm_ratio_release(mm_ctx *ctx);
+int mm_ratio_reserve(mm_ctx *ctx, size_t n_runs, size_t batch_capacity);
+int mm_ratio_handoff(mm_ctx *src, mm_ctx *dst, uint32_t chunk, uint32_t n_chunks);
 
 /* ---- one input on several GPUs (replaces the reference's thread-per-file pool, mmannot.cpp:2117-2143, which can only
  * spread whole files).  One context per device, each on its own copy of the index.

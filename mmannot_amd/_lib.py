@@ -79,6 +79,12 @@ SYMBOLS = {
     "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mm_ratio_pending": (C.c_size_t, [C.c_void_p]),
+    "mm_table_export_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm_table_import_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
+    "mm_ratio_replay": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32]),
+    "mm_ratio_release": (C.c_int, [C.c_void_p]),
+    "mm_ratio_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
+    "mm_ratio_handoff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "mm_ratio_resolve_chunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "mm_row_chunk": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "mm_partition": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -303,6 +303,30 @@ class Counter:
         """Replay the parked batches for the rows of one chunk only (see row_chunk); the last chunk releases them."""
         check(lib().mm_ratio_resolve_chunk(self._h, int(chunk), int(n_chunks)))
 
+    # ---- the same chain with the table staying on the device (asynchronous on the context's stream; see include/mmannot_amd.h)
+    TABLE_SLOTS = 65536
+
+    def export_table_device(self, keys_ptr: int, sums_ptr: int):
+        check(lib().mm_table_export_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(sums_ptr)))
+
+    def import_table_device(self, keys_ptr: int, sums_ptr: int, n: int = 65536, chunk: int = 0, n_chunks: int = 1):
+        check(lib().mm_table_import_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(sums_ptr), int(n), int(chunk), int(n_chunks)))
+
+    def ratio_replay(self, first: int = 0, count: int = 1 << 62, chunk: int = 0, n_chunks: int = 1):
+        check(lib().mm_ratio_replay(self._h, int(first), int(count), int(chunk), int(n_chunks)))
+
+    def ratio_release(self):
+        check(lib().mm_ratio_release(self._h))
+
+    def ratio_reserve(self, n_runs: int, batch_capacity: int):
+        check(lib().mm_ratio_reserve(self._h, int(n_runs), int(batch_capacity)))
+
+    def ratio_handoff_to(self, other: "Counter", chunk: int = 0, n_chunks: int = 1):
+        check(lib().mm_ratio_handoff(self._h, other._h, int(chunk), int(n_chunks)))
+
+    def ratio_pending(self) -> int:
+        return int(lib().mm_ratio_pending(self._h))
+
     def hit_masks(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint64)
         check(lib().mm_get_hit_masks(self._h, out.ctypes.data, n))

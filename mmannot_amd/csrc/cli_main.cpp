@@ -100,6 +100,12 @@ struct GlibcRand {
 // Host staging of the tuple stream: three pinned buffers (hipHostMalloc through the C ABI).  The decoder fills one while the
 // library's copy stream drains the two submitted before it (a host buffer is free again once the second-next
 // mm_annotate_batch has returned), so H2D copies, kernels and decoding overlap and nothing waits per batch.
+// closes a reads decoder when the scope that opened it ends, however it ends
+struct ReaderGuard {
+  mm_reader **rd;
+  ~ReaderGuard() { if (rd && *rd) { mm_reader_close(*rd); *rd = nullptr; } }
+};
+
 struct Staging {
   // tuples per batch (2^21: the decoder, not the device, sets the pace of a run from files, and hands over smaller batches sooner -
   // measured on a 16.8 M-record BAM against 2^22: 0.53 s instead of 0.60); MM_CLI_BATCH overrides it (tests: many small batches
@@ -382,6 +388,7 @@ int main(int argc, char **argv) {
     if (ctx && mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, read_stats);
+    ReaderGuard rd_guard{&rd};                               // (the reader's threads and its mapping go on every way out of here)
     if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
     // host bookkeeping for -m / -M / -y random
     std::unordered_map<uint32_t, PendingRead> pending;
@@ -437,7 +444,7 @@ int main(int argc, char **argv) {
       { std::lock_guard<std::mutex> lk(table_mu); t_decode += secs(t0, t1); n_records += n; }
       if (!ctx) {   // (before the end-of-file test: an empty file still needs its context for the report)
         ctx = late_ctx();
-        if (!ctx) { mm_reader_close(rd); return EXIT_FAILURE; }
+        if (!ctx) return EXIT_FAILURE;
         if (mm_reset(ctx) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
       }
       if (n == 0) break;
@@ -551,7 +558,7 @@ int main(int argc, char **argv) {
       for (size_t q = 0; q < rnd_seen.size(); ++q) if (rnd_seen[q] & 1) rnd.seen[mm_reader_name(rd, (uint32_t) q)] = true;
       for (auto &e : rnd_choice) rnd.choice[mm_reader_name(rd, e.first)] = e.second;
     }
-    mm_reader_close(rd);
+    mm_reader_close(rd); rd = nullptr;
     return 0;
   };
   // One input file on several devices (--devices a,b,... with a single -r file).  -y default / unique: the tuples
@@ -563,6 +570,7 @@ int main(int argc, char **argv) {
     for (mm_ctx *c : ctxs) if (mm_reset(c) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     mm_reader *rd = nullptr;
     int rc = mm_reader_open(&rd, reads[fi].c_str(), format, an, strand_compat, strategy == MM_STRAT_UNIQUE, false);
+    ReaderGuard rd_guard{&rd};
     if (rc != MM_OK) { err << mm_reader_take_log(rd) << mm_reader_error(rd) << std::endl; return EXIT_FAILURE; }
     std::vector<std::unique_ptr<Staging>> stg_own;  // per device: three pinned buffers of a full batch
     for (size_t d = 0; d < N; ++d) stg_own.emplace_back(new Staging(3));
@@ -596,7 +604,13 @@ int main(int argc, char **argv) {
       } else {
         for (size_t d = 0; d < N; ++d) { part_out[d] = stg(d).buf[submitted[d] % 3]; part_big[d] = stg(d).big.data(); }
         if (mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg(0).big.size(), part_nbig.data(),
-                         part_max.data(), part_qlo.data()) != MM_OK) { err << "mmannot-amd: cannot deal the batch out to the devices" << std::endl; return EXIT_FAILURE; }
+                         part_max.data(), part_qlo.data()) != MM_OK) {
+          const int prc = mm_partition(aln, n, big.data(), n_big, (int) N, part_out.data(), part_n.data(), part_big.data(), stg(0).big.size(), part_nbig.data(), nullptr, nullptr);
+          err << "mmannot-amd: cannot deal the batch out to the devices: "
+              << (prc == MM_ERR_RANGE ? "a device's share of the NH side list (NH >= 2047) does not fit its staging list"
+                                      : (prc == MM_ERR_ARG ? "a tuple's NH field says 'see the side list' but the list has no entry for it" : "internal error")) << std::endl;
+          return EXIT_FAILURE;
+        }
         const uint64_t qb = (mm_reader_qid_bound(rd) + N - 1) / N;
         for (size_t d = 0; d < N; ++d) {
           if (part_n[d] == 0) continue;
@@ -620,7 +634,7 @@ int main(int argc, char **argv) {
     if (nr && mm_merge(ctxs.data(), (int) N, strategy, masks.data(), sums.data(), nr, &nr, st) != MM_OK) { err << "mmannot-amd: " << mm_last_error() << std::endl; return EXIT_FAILURE; }
     masks.resize(nr); sums.resize(nr);
     report(fi, st, masks, sums, err, nullptr);
-    mm_reader_close(rd);
+    mm_reader_close(rd); rd = nullptr;
     return 0;
   };
   int rc_all = 0;

@@ -191,7 +191,10 @@ struct ProbeParams {
   const u32 *slotBits;      // one bit per slot: does it hold any record?  NULL when too few slots are empty for the test to pay
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
   const uint4 *fslots;      // fast slots: 32 B per bin (see mm_index_create); NULL = none
-  const u32 *fbits;         // one bit per fast slot: any record (or the overflow mark)?
+  const u32 *fbits;         // the map, 2 bits per fast slot: FS_EMPTY, FS_GENERAL (fetch the slot), FS_COVERED (the answer is in fcls)
+  u32 fextClass[3];         // extension blocks numbered below these hold at most 11 / 15 / 23 records (3 / 4 / 6 quads to request)
+  const uint4 *fext;        // extension blocks: 128 B = count + up to 31 records, for the bins whose slot says FS_OVERFLOW | block
+  const u32 *fcls;          // one byte per 8 fast slots (four to a word): element:6 | ok('+'):1 | ok('-'):1 of the covering interval
   const uint2 *fchr;        // per chromosome {first fast slot, number of fast slots}
   u32 fLmax;                // longest read the fast slots answer exactly
   u32 fshift, freach;       // the fast slots' own bin width and reach
@@ -444,10 +447,13 @@ __device__ __forceinline__ void last_of_type(const ProbeParams &P, const Cand &c
 #define REC_LONG (1u << 30)
 // fast slots (4-byte bin-relative records, see mm_index_create): usable up to this bin shift - beyond it the saturating length field
 // (24 - shift - 1 bits) is shorter than a bin
-#define FS_MAX_SHIFT 11
+#define FS_MAX_SHIFT 10
 #define FS_MIN_SHIFT 7
 #define FS_OVERFLOW_SHARE 0.01      // bins holding more than 7 records: above this share the fast table takes half the bin width
 #define FS_OVERFLOW 0x80000000u     // header: more than 7 records - the tuple takes the 8-byte slots
+#define FS_EXT_NONE 0x7FFFFu         // ... | extension block (19 bits: it travels beside a 13-bit tile-local index), this value = none
+#define FS_EXT_RECORDS 31u
+enum { FS_EMPTY = 0, FS_GENERAL = 1, FS_COVERED = 2 };   // codes of the fast slots' map
 
 template <int OVL>
 __device__ __forceinline__ bool rec_pass(const ProbeParams &P, u32 rx, u32 ry, int s, int e, int rstrand, u32 &o, int &ie) {
@@ -533,7 +539,9 @@ __device__ __forceinline__ u32 slot_reach_count(const ProbeParams &P, u32 w1) {
   }
 
 // scan() + getFirst() through the compact index, for a read with e >= s.
-template <int OVL>
+// EAGER (k_probe_list: every tuple is a heavy one and few are in flight - what counts is the length of the chain of dependent loads):
+// no look at the bitmap of non-empty slots, the whole 64-byte slot requested at once, long lists eight records at a time
+template <int OVL, bool EAGER = false>
 __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *chrSlot, const u64 *lineMask, int s, int e, u32 tid1, int rstrand,
                                             u32 &walked) {
   if (tid1 == 0 || tid1 > P.nchr) return 0;
@@ -559,9 +567,11 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
     if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) hit |= 1ull << REC_TYPE(RY); \
   }
   for (u32 b_ = b0; b_ <= bl; ++b_) {
-    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue;
+    if (!EAGER && P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue;
     const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;
     const uint4 q0 = S_[0], q1 = S_[1];
+    uint4 q2 = make_uint4(0u, 0u, 0u, 0u), q3 = q2;
+    if (EAGER) { q2 = S_[2]; q3 = S_[3]; }
     const u32 nAct_ = q0.x & 0xffffu;
     u32 n_ = nAct_ + (q0.x >> 16);
     if (reach_) n_ += slot_reach_count(P, q0.y);
@@ -578,7 +588,7 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
     MM_TEST(q1.x, q1.y, e1, first_ <= 1 && n_ > 1)
     MM_TEST(q1.z, q1.w, e2, first_ <= 2 && n_ > 2)
     if (n_ > 3) {
-      const uint4 q2 = S_[2], q3 = S_[3];
+      if (!EAGER) { q2 = S_[2]; q3 = S_[3]; }
       int e3 = (int) q2.x + (int) (q2.y & REC_LEN_MASK), e4 = (int) q2.z + (int) (q2.w & REC_LEN_MASK),
           e5 = (int) q3.x + (int) (q3.y & REC_LEN_MASK), e6 = (int) q3.z + (int) (q3.w & REC_LEN_MASK);
       if ((q2.y | q2.w | q3.y | q3.w) & REC_LONG) {
@@ -592,8 +602,17 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
       MM_TEST(q3.x, q3.y, e5, first_ <= 5 && n_ > 5)
       MM_TEST(q3.z, q3.w, e6, first_ <= 6 && n_ > 6)
       if (n_ > 7) {
-        for (u32 k_ = max(7u, first_); k_ < n_; k_ += 4) {   // rare long lists: four loads in flight
-          const uint2 *F_ = P.flat + q0.y;
+        const uint2 *F_ = P.flat + q0.y;
+        u32 k_ = max(7u, first_);
+        if (EAGER) for (; k_ + 4 < n_; k_ += 8) {            // eight loads in flight
+          const uint2 r0 = F_[k_], r1 = F_[k_ + 1], r2 = F_[k_ + 2], r3 = F_[k_ + 3], r4 = F_[k_ + 4], r5 = F_[min(k_ + 5, n_ - 1)],
+                      r6 = F_[min(k_ + 6, n_ - 1)], r7 = F_[min(k_ + 7, n_ - 1)];
+          MM_VISIT1(r0.x, r0.y) MM_VISIT1(r1.x, r1.y) MM_VISIT1(r2.x, r2.y) MM_VISIT1(r3.x, r3.y) MM_VISIT1(r4.x, r4.y)
+          if (k_ + 5 < n_) MM_VISIT1(r5.x, r5.y)
+          if (k_ + 6 < n_) MM_VISIT1(r6.x, r6.y)
+          if (k_ + 7 < n_) MM_VISIT1(r7.x, r7.y)
+        }
+        for (; k_ < n_; k_ += 4) {   // rare long lists: four loads in flight
           const uint2 r0 = F_[k_], r1 = F_[min(k_ + 1, n_ - 1)], r2 = F_[min(k_ + 2, n_ - 1)], r3 = F_[min(k_ + 3, n_ - 1)];
           MM_VISIT1(r0.x, r0.y)
           if (k_ + 1 < n_) MM_VISIT1(r1.x, r1.y)
@@ -732,12 +751,12 @@ __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool ok, bool skewe
 }
 
 // scan() + getFirst() of one tuple: read strand from -s (strandF / strandR / strandU, mmannot.cpp:836-844), then the index
-template <int OVL>
+template <int OVL, bool EAGER = false>
 __device__ __forceinline__ u64 probe_tuple(const ProbeParams &P, bool useSlots, const uint2 *chrSlot, const u64 *sLine, const int4 a, u32 &walked) {
   const int rec_strand = a.z & 1;
   const int rstrand = (P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1));
   // reads without CIGAR operations (end < start) need the 'leading isBefore run' rule and take the full structure
-  return (useSlots && a.y >= a.x) ? probe_slots<OVL>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
+  return (useSlots && a.y >= a.x) ? probe_slots<OVL, EAGER>(P, chrSlot, sLine, a.x, a.y, TSN_TID1(a.z), rstrand, walked)
                                     : probe_one<OVL>(P, a.x, a.y, TSN_TID1(a.z), rstrand, walked);
 }
 
@@ -965,7 +984,28 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_sets(const ProbePar
 // more than 7 records in the bin, a read that spans further than its slot's reach, is longer than the saturating fields allow or has
 // no CIGAR operations, the second selection pass (several elements of the winning Order line: mmannot.cpp:1049-1075) - is not done
 // here: the tuple's index goes to a list (a region per wave: no atomics) and k_probe_list walks it with k_probe's code right after.
-#define FS_LT_CAP 128u
+#define FS_LT_CAP 64u
+// LDS-DMA: 16 bytes per lane from base + off (bytes, per lane) to the LDS address LDS + 16 x lane; MM_GLDS32: the next 16 bytes too, to
+// LDS2 + 16 x lane.  M0 (the LDS base of the transfer) is the compiler's: saved and put back inside the statement that uses it.
+#define MM_GLDS16(BASE, OFF, LDS, CACHE)                                                                                       \
+  {                                                                                                                            \
+    u32 keep_;                                                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" CACHE "\n\ts_mov_b32 m0, %0"  \
+                 : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS) : "memory");                                                   \
+  }
+#define MM_GLDS4(BASE, OFF, LDS)                                                                                               \
+  {                                                                                                                            \
+    u32 keep_;                                                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"             \
+                 : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS) : "memory");                                                   \
+  }
+#define MM_GLDS32(BASE, OFF, LDS, LDS2)                                                                                        \
+  {                                                                                                                            \
+    u32 keep_;                                                                                                                 \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"                      \
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:16\n\ts_mov_b32 m0, %0"                  \
+                 : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS), "s"((LDS2) - 16u) : "memory");                                \
+  }
 template <int OVL, int VAR>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_fast(const ProbeParams P, const int4 *__restrict__ aln, int single, u32 qlo, size_t n,
                                                                   u32 *__restrict__ gkey, u32 *__restrict__ gpay, u32 *__restrict__ info, GlobalTable G,
@@ -985,9 +1025,10 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_fast(const ProbePar
   // wait on them is written out below): lane t's slot is S[0][t], S[1][t]; its next tuple is TU[t]
   __shared__ uint4 S[2][256];
   __shared__ uint4 TU[256];
+  __shared__ u32 CW[256];               // the word of fcls holding the class byte of a covered bin
   const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < 64) sLine[t] = P.lineMask[t];
-  for (u32 c = t; c < min(P.nchr, (u32) MM_LDS_CHR); c += 256) sChr[c] = P.fchr[c];
+  for (u32 c = t; c < (u32) MM_LDS_CHR; c += 256) sChr[c] = c < P.nchr ? P.fchr[c] : make_uint2(0u, 0u);   // (beyond the last chromosome: no bins)
   lds_table_init(T);
   if (t < 8) sstat[t] = 0;
   if (t < 3) sq[t] = 0;
@@ -995,123 +1036,185 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_fast(const ProbePar
   __syncthreads();
   const bool uniqueOnly = VAR == PV_COUNT && P.strategy == MM_STRAT_UNIQUE;
   const size_t first = (size_t) blockIdx.x * RS_TILE;
-  const size_t last = min(n, first + (size_t) RS_TILE);
-  const int nit = (int) ((last - first + 255) / 256);
-  const u32 sshift = P.fshift, soMask = (2u << sshift) - 1u;
+  const u32 cnt = (u32) (min(n, first + (size_t) RS_TILE) - first);      // tuples of this tile; everything below is tile-local (32-bit offsets)
+  const int nit = (int) ((cnt + 255u) / 256u);
+  const int4 *const alnT = aln + first;
+  u32 *const gkeyT = haveKey ? gkey + first : nullptr, *const gpayT = haveKey ? gpay + first : nullptr;
+  const u32 sshift = P.fshift, soMask = (2u << sshift) - 1u, Wm1 = (1u << sshift) - 1u, freach = P.freach;
   const u32 ldsS = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (size_t) &S[0][t & ~63u]);   // this wave's KiB of S[0]; S[1] lies 4 KiB behind
   const u32 ldsT = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (size_t) &TU[t & ~63u]);
+  const u32 ldsC = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (size_t) &CW[t & ~63u]);
+  const u64 updown = P.elemUp | P.elemDown;
   ProbeAcc A;
-  u32 dn = 0;                                            // tuples this wave has passed on so far
+  u32 dn = 0, en = 0;                                    // tuples this wave has passed on so far: to k_probe_list / to its own extension pass
   u32 *const dl = dlist + first + (size_t) w * (RS_TILE / 4);
 
-  // stage "locate" of a tuple: which slot, may this kernel answer it, is the slot empty; requests the slot's 32 bytes and the tuple
-  // two iterations ahead.  fl: bit 0 = has a tuple, 1 = skipped by -y unique, 2 = passed on, 3 = slot requested
+  // stage "locate" of tuple li (tile-local index): which slot, may this kernel answer it, is the slot empty; requests the slot's 32
+  // bytes and tuple li + 256.  FL: bit 0 = has a tuple, 1 = skipped by -y unique, 2 = passed on, 3 = slot requested, 4 = covered bin (class word
+  // requested), bits 8-9 = which byte of that word
   int4 a0 = make_int4(0, 0, 0, 0), a1 = a0;            // tuple it (located, its slot requested), it + 1 (loaded)
   u32 fl0 = 0;
   int bs0 = 0;                                           // first base of tuple it's bin
-#define MM_FAST_LOCATE(A_, I_, FL_, BS_, I2_)                                                                         \
+#define MM_FAST_LOCATE(A_, LI_, FL_, BS_)                                                                             \
   {                                                                                                                  \
     /* straight-line up to the bitmap word: a load whose use sits in another branch than the load makes the compiler wait with \
        vmcnt(0) where the branches join - behind our requests, which that wait would then drain */                    \
-    const bool val_ = (I_) < last;                                                                                   \
-    const u32 tid1_ = TSN_TID1((A_).z);                                                                              \
+    const bool val_ = (LI_) < cnt;                                                                                   \
+    const u32 tid0_ = TSN_TID1((A_).z) - 1u;            /* chromosome; 0xFFFFFFFF = unknown to the annotation */     \
     const u32 nhf_ = ((u32) (A_).z >> 1) & MM_ALN_NH_ESCAPE;                                                         \
-    const bool known_ = val_ && tid1_ != 0 && tid1_ <= P.nchr;                                                       \
-    const uint2 cs_ = sChr[known_ ? tid1_ - 1 : 0];                                                                  \
-    const u32 nb_ = known_ ? cs_.y : 0u;                                                                             \
-    const u32 sb_ = (u32) (A_).x >> sshift, eb_ = (u32) (A_).y >> sshift, ebc_ = min(eb_, nb_ - 1);                  \
-    const bool one_ = ebc_ == sb_ || (ebc_ == sb_ + 1 && eb_ == ebc_ && (u32) (A_).y - (ebc_ << sshift) < P.freach); \
+    const uint2 cs_ = sChr[min(tid0_, (u32) MM_LDS_CHR - 1u)];                                                       \
+    const u32 nb_ = (val_ && tid0_ < P.nchr) ? cs_.y : 0u;                                                           \
+    const u32 sb_ = (u32) (A_).x >> sshift, db_ = ((u32) (A_).y >> sshift) - sb_;                                    \
+    /* one slot serves the read: it ends in its bin, or in the reach behind it, or the bin is the chromosome's last */ \
+    const bool one_ = db_ == 0 || sb_ + 1 == nb_ || (db_ == 1 && ((u32) (A_).y & Wm1) < freach);                     \
     const bool skip_ = val_ && uniqueOnly && nhf_ != 1u;                                                             \
     const bool esc_ = nhf_ == MM_ALN_NH_ESCAPE;        /* NH in the side list: a dependent load - not in this loop */ \
-    const bool look_ = nb_ != 0 && !skip_;                                                                           \
-    const bool elig_ = look_ && !esc_ && (A_).y >= (A_).x && sb_ < nb_ && (u32) ((A_).y - (A_).x) < P.fLmax && one_; \
+    /* (a read that starts behind the chromosome's last bin starts behind every interval's end: no interval includes or overlaps it) */ \
+    const bool look_ = nb_ != 0 && !skip_ && (sb_ < nb_ || (A_).y < (A_).x);                                         \
+    const bool elig_ = look_ && !esc_ && (A_).y >= (A_).x && one_;                                                   \
     const bool pass_ = val_ && !skip_ && (esc_ || (look_ && !elig_));                                                \
     const u32 slot_ = elig_ ? cs_.x + sb_ : 0u;                                                                      \
     BS_ = (int) (sb_ << sshift);                                                                                     \
-    const u32 bw_ = P.fbits[slot_ >> 5];                                                                             \
-    const bool full_ = elig_ && ((bw_ >> (slot_ & 31u)) & 1u);                                                       \
-    FL_ = (val_ ? 1u : 0u) | (skip_ ? 2u : 0u) | (pass_ ? 4u : 0u) | (full_ ? 8u : 0u);                              \
-    if (full_) {                                                                                                     \
-      const uint4 *src_ = P.fslots + (size_t) slot_ * 2, *src1_ = src_ + 1;                                          \
-      u32 keep_;                                                                                                     \
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"         \
-                   "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"              \
-                   : "=&s"(keep_) : "v"(src_), "v"(src1_), "s"(ldsS), "s"(ldsS + 4096u) : "memory");                 \
+    const u32 mw_ = P.fbits[slot_ >> 4];                                                                             \
+    const u32 code_ = elig_ ? (mw_ >> ((slot_ & 15u) << 1)) & 3u : 0u;                                              \
+    FL_ = (val_ ? 1u : 0u) | (skip_ ? 2u : 0u) | (pass_ ? 4u : 0u) | (code_ == FS_GENERAL ? 8u : 0u) | (code_ == FS_COVERED ? 16u : 0u) | ((slot_ & 24u) << 5); \
+    if (code_ == FS_GENERAL) {                                                                                       \
+      const u32 o_ = slot_ << 5;                                                                                     \
+      MM_GLDS32(P.fslots, o_, ldsS, ldsS + 4096u)                                                                    \
     }                                                                                                                \
-    if ((I2_) < last) {                                                                                              \
-      const int4 *src_ = aln + (I2_);                                                                                \
-      u32 keep_;                                                                                                     \
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" \
-                   : "=&s"(keep_) : "v"(src_), "s"(ldsT) : "memory");                                                \
-    }                                                                                                                \
+    if (code_ == FS_COVERED) { const u32 o_ = (slot_ >> 3) & ~3u; MM_GLDS4(P.fcls, o_, ldsC) }                       \
+    if ((LI_) + 256u < cnt) { const u32 o_ = ((LI_) + 256u) << 4; MM_GLDS16(alnT, o_, ldsT, " nt") }                 \
   }
   // prologue: tuple 0 located and its slot requested, tuple 1 requested
-  if (first + t < last) a0 = ld_stream(aln + first + t);
-  MM_FAST_LOCATE(a0, first + t, fl0, bs0, first + 256 + t)
-  u32 pkey = 0, ppay = 0;
-  size_t pi = (size_t) -1;                               // outputs of the previous tuple, stored one iteration late (see below)
+  if (t < cnt) a0 = ld_stream(alnT + t);
+  MM_FAST_LOCATE(a0, t, fl0, bs0)
+  u32 pkey = 0, ppay = 0, pli = 0;
+  bool pend = false;                                     // outputs of the previous tuple, stored one iteration late (see below)
   for (int it = 0; it < nit; ++it) {
-    const size_t i = first + (size_t) it * 256 + t;
+    const u32 li = (u32) it * 256u + t;
     // slot(it) and tuple(it+1) are in LDS: everything requested so far has arrived
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint4 q0 = S[0][t], q1 = S[1][t];
+    const u32 cw = CW[t];
     { const uint4 u = TU[t]; a1 = make_int4((int) u.x, (int) u.y, (int) u.z, (int) u.w); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next requests may land in S / TU right away)
     // the previous tuple's outputs go out now, ahead of this iteration's requests: at the loop's wait they are the oldest and long done
     // (stores count in vmcnt like loads, in issue order - issued last they would be what every wave waits for)
-    if (haveKey && pi != (size_t) -1) { gkey[pi] = pkey; gpay[pi] = ppay; }
+    if (haveKey && pend) { gkeyT[pli] = pkey; gpayT[pli] = ppay; }
     // tuple it+1: locate, bitmap word, slot request; tuple it+2: request
     u32 fl1; int bs1;
-    MM_FAST_LOCATE(a1, i + 256, fl1, bs1, i + 512)
-    // ---- tuple `it` against its slot
+    MM_FAST_LOCATE(a1, li + 256u, fl1, bs1)
+    // ---- tuple `it` against its slot: straight-line - seven records, the unused ones zero (no ok bit: they pass nothing)
     const bool valid = (fl0 & 1u) != 0;
     u32 nh = ((u32) a0.z >> 1) & MM_ALN_NH_ESCAPE;
     if (single && valid && nh > 1) { atomicCAS(G.err, 0u, (u32) ERR_SINGLE_HIT); nh = 1; }   // MM_BATCH_SINGLE_HIT was a promise
-    bool defer = (fl0 & 4u) != 0;
-    u64 mask = 0;
-    if (fl0 & 8u) {
-      if (q0.x & FS_OVERFLOW) defer = true;
-      else {
-        const int rec_strand = a0.z & 1;
-        const u32 okbit = 24u + (u32) ((P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1)));
-        const int sr = a0.x - bs0, er = a0.y - bs0;       // the read relative to its bin (sr >= 0)
-        const u32 nA = q0.x & 15u, nR = (q0.x >> 4) & 15u;
-        u64 hit = 0;
-#define MM_FAST_TEST(J, R)                                                                                       \
+    const bool have = (fl0 & 8u) != 0;
+    const bool ovf = have && (q0.x & FS_OVERFLOW) != 0;
+    const int rec_strand = a0.z & 1;
+    const u32 okbit = 24u + (u32) ((P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1)));
+    const int sr = a0.x - bs0, er = a0.y - bs0;           // the read relative to its bin (sr >= 0)
+    u64 hit = 0;
+#define MM_FAST_TEST(R)                                                                                           \
   {                                                                                                              \
-    const u32 r_ = (R), pl_ = r_ & 0xFFFFFFu;                                                                    \
-    const bool act_ = (J) < nA;                                                                                  \
-    const int so_ = act_ ? 0 : (int) (pl_ & soMask);                                                             \
-    const int ie_ = act_ ? (int) pl_ : so_ + (int) (pl_ >> (sshift + 1));                                        \
-    hit |= (u64) ((u32) ((J) < nR) & span_pass<OVL>(P, so_, ie_, (r_ >> okbit) & 1u, sr, er)) << (r_ >> 26);    \
+    const u32 r_ = (R);                                                                                          \
+    hit |= (u64) span_pass<OVL>(P, (int) (r_ & soMask), (int) ((r_ & 0xFFFFFFu) >> (sshift + 1)), (r_ >> okbit) & 1u, sr, er) << (r_ >> 26); \
   }
-        MM_FAST_TEST(0u, q0.y) MM_FAST_TEST(1u, q0.z) MM_FAST_TEST(2u, q0.w)
-        if (nR > 3) { MM_FAST_TEST(3u, q1.x) MM_FAST_TEST(4u, q1.y) MM_FAST_TEST(5u, q1.z) MM_FAST_TEST(6u, q1.w) }
+    MM_FAST_TEST(q0.y) MM_FAST_TEST(q0.z) MM_FAST_TEST(q0.w) MM_FAST_TEST(q1.x) MM_FAST_TEST(q1.y) MM_FAST_TEST(q1.z) MM_FAST_TEST(q1.w)
 #undef MM_FAST_TEST
-        if (hit) {   // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts
-          const u64 cand = hit & sLine[__ffsll((long long) hit) - 1];
-          // one element, or inclusion without "upstream" / "downstream" elements (every passing interval has overlap 1, distance 0: all tie)
-          if ((cand & (cand - 1)) == 0 || (OVL == MM_OVL_INCLUSION && !(cand & (P.elemUp | P.elemDown)))) mask = cand;
-          else defer = true;                               // max overlap / min distance over last writers: k_probe_list
-        }
+    if (!have || ovf) hit = 0;                             // (a lane without a slot has read stale LDS)
+    {                                                      // a covered bin: one interval, open at the bin's left edge, reaching past every read served here
+      const u32 cb = (fl0 & 16u) ? (cw >> ((fl0 >> 5) & 24u)) & 0xFFu : 0u;
+      const u32 r_ = (cb << 24) | (0xFFFFFFu & ~soMask);
+      hit |= (u64) span_pass<OVL>(P, 0, (int) (0xFFFFFFu >> (sshift + 1)), (r_ >> okbit) & 1u, sr, er) << (r_ >> 26);
+    }
+    // getFirst (mmannot.cpp:1029-1076): only the first Order line holding a hit element counts; one element, or inclusion without
+    // "upstream" / "downstream" elements (every passing interval has overlap 1, distance 0: all tie) is settled here - max overlap /
+    // min distance over last writers is k_probe_list's
+    const u64 cand = hit & sLine[(__ffsll((long long) hit) - 1) & 63];
+    const bool settled = (cand & (cand - 1)) == 0 || (OVL == MM_OVL_INCLUSION && !(cand & updown));
+    const u64 mask = settled ? cand : 0ull;
+    const bool ext = ovf && (q0.x & FS_EXT_NONE) != FS_EXT_NONE;      // the bin's records are in an extension block: this kernel's own later pass
+    const u32 xblk = q0.x & FS_EXT_NONE;
+    const bool defer = (fl0 & 4u) != 0 || ovf || !settled;              // not answered in this iteration
+    const bool processed = valid && !(fl0 & 2u) && !defer;
+    {                                                      // pass the tuple on: this wave's region, no atomics - k_probe_list's from the front, ours from the back
+      const u64 dm = __ballot(defer && !ext), em = __ballot(ext);
+      if (dm | em) {
+        const u64 below = (1ull << lane) - 1ull;
+        if (defer && !ext) dl[dn + (u32) __popcll(dm & below)] = (u32) (first + li);
+        if (ext) dl[RS_TILE / 4 - 1 - (en + (u32) __popcll(em & below))] = li | (xblk << 13);
+        dn += (u32) __popcll(dm); en += (u32) __popcll(em);
       }
     }
-    const bool processed = valid && !(fl0 & 2u) && !defer;
-    {                                                      // pass the tuple on: this wave's region of the list, no atomics
+    u32 key, pay;
+    tuple_tail(grouped_strategy, ratio, false, useHist ? HIST_LDS : HIST_NONE, T, sHist, hist, nblk, G, qlo, lane, first + li, a0, nh, processed, mask, A, key, pay);
+    pend = valid && !defer;                                // (k_probe_list writes the outputs of the tuples it is handed)
+    pli = li; pkey = key; ppay = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
+    a0 = a1; fl0 = fl1; bs0 = bs1;
+  }
+#undef MM_FAST_LOCATE
+  if (haveKey && pend) { gkeyT[pli] = pkey; gpayT[pli] = ppay; }
+  // ---- the tuples on bins with 8 to 31 records: one more pass per 64 of them - tuple and extension block requested together, the block's
+  // records tested like a slot's.  (A chain of two loads at the end of the workgroup's life, where k_probe_list would walk the 8-byte
+  // slots and their lists behind a kernel boundary: five to ten dependent loads.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (this wave's writes to its region)
+  for (u32 base = 0; base < en; base += 64) {
+    const bool valid = base + lane < en;
+    // (from the region's lower end: what this pass still hands to k_probe_list is appended to the front part, which may then grow over
+    // entries of this pass and of earlier ones only)
+    const u32 ent = valid ? __builtin_nontemporal_load(dl + (RS_TILE / 4 - en + base + lane)) : 0u;
+    const u32 li = ent & (RS_TILE - 1u);
+    int4 a = make_int4(0, 0, 0, 0);
+    uint4 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = make_uint4(0u, 0u, 0u, 0u);
+    const u32 xb = ent >> 13;
+    const u32 nq = !valid ? 0u : (xb < P.fextClass[0] ? 3u : (xb < P.fextClass[1] ? 4u : (xb < P.fextClass[2] ? 6u : 8u)));   // quads of the block that hold records
+    if (valid) {
+      a = alnT[li];
+      const uint4 *E = P.fext + (size_t) xb * 8;
+      x[0] = E[0]; x[1] = E[1]; x[2] = E[2];
+      if (nq > 3) x[3] = E[3];
+      if (nq > 4) { x[4] = E[4]; x[5] = E[5]; }
+      if (nq > 6) { x[6] = E[6]; x[7] = E[7]; }
+    }
+    const u32 nh = ((u32) a.z >> 1) & MM_ALN_NH_ESCAPE;   // (not the escape value, and within the MM_BATCH_SINGLE_HIT promise: checked in the main loop)
+    const int bs = (int) (((u32) a.x >> sshift) << sshift);
+    const int rec_strand = a.z & 1;
+    const u32 okbit = 24u + (u32) ((P.strandedness == MM_STRANDED_U) ? 1 : ((P.strandedness == MM_STRANDED_F) ? rec_strand : (rec_strand ^ 1)));
+    const int sr = a.x - bs, er = a.y - bs;
+    u64 hit = 0;
+#define MM_FAST_TEST(R)                                                                                           \
+  {                                                                                                              \
+    const u32 r_ = (R);                                                                                          \
+    hit |= (u64) span_pass<OVL>(P, (int) (r_ & soMask), (int) ((r_ & 0xFFFFFFu) >> (sshift + 1)), (r_ >> okbit) & 1u, sr, er) << (r_ >> 26); \
+  }
+    MM_FAST_TEST(x[0].y) MM_FAST_TEST(x[0].z) MM_FAST_TEST(x[0].w)
+#pragma unroll
+    for (int k = 1; k < 3; ++k) { MM_FAST_TEST(x[k].x) MM_FAST_TEST(x[k].y) MM_FAST_TEST(x[k].z) MM_FAST_TEST(x[k].w) }
+    if (__ballot(nq > 3)) {                                // (wave-uniform; quads that were not requested are zero: they pass nothing)
+      MM_FAST_TEST(x[3].x) MM_FAST_TEST(x[3].y) MM_FAST_TEST(x[3].z) MM_FAST_TEST(x[3].w)
+      if (__ballot(nq > 4)) {
+#pragma unroll
+        for (int k = 4; k < 8; ++k) { MM_FAST_TEST(x[k].x) MM_FAST_TEST(x[k].y) MM_FAST_TEST(x[k].z) MM_FAST_TEST(x[k].w) }
+      }
+    }
+#undef MM_FAST_TEST
+    const u64 cand = hit & sLine[(__ffsll((long long) hit) - 1) & 63];
+    const bool settled = (cand & (cand - 1)) == 0 || (OVL == MM_OVL_INCLUSION && !(cand & updown));
+    const u64 mask = settled ? cand : 0ull;
+    const bool defer = valid && !settled;
+    {
       const u64 dm = __ballot(defer);
       if (dm) {
-        if (defer) dl[dn + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = (u32) i;
+        if (defer) dl[dn + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = (u32) (first + li);
         dn += (u32) __popcll(dm);
       }
     }
     u32 key, pay;
-    tuple_tail(grouped_strategy, ratio, false, useHist ? HIST_LDS : HIST_NONE, T, sHist, hist, nblk, G, qlo, lane, i, a0, nh, processed, mask, A, key, pay);
-    pi = (valid && !defer) ? i : (size_t) -1;              // (k_probe_list writes the outputs of the tuples it is handed)
-    pkey = key; ppay = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16));
-    a0 = a1; fl0 = fl1; bs0 = bs1;
+    tuple_tail(grouped_strategy, ratio, false, useHist ? HIST_LDS : HIST_NONE, T, sHist, hist, nblk, G, qlo, lane, first + li, a, nh, valid && !defer, mask, A, key, pay);
+    if (haveKey && valid && !defer) { gkeyT[li] = key; gpayT[li] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16)); }
   }
-#undef MM_FAST_LOCATE
-  if (haveKey && pi != (size_t) -1) { gkey[pi] = pkey; gpay[pi] = ppay; }
   // the four waves' regions -> one list for the whole batch (one atomic per workgroup), so that k_probe_list runs on full wavefronts
   __shared__ u32 wcnt[4], wbase[4];
   if (lane == 0) wcnt[w] = dn;
@@ -1136,15 +1239,19 @@ template <int OVL>
 __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_list(const ProbeParams P, const int4 *__restrict__ aln, const uint2 *__restrict__ big, u32 nbig,
                                                                   int single, u32 qlo, u32 *__restrict__ gkey, u32 *__restrict__ gpay, u32 *__restrict__ info,
                                                                   GlobalTable G, u64 *__restrict__ stats, u32 *__restrict__ hist, u32 nblk,
-                                                                  const u32 *__restrict__ dlist, const u32 *__restrict__ dcnt, u64 *__restrict__ walkstat) {
+                                                                  const u32 *__restrict__ dlist, const u32 *__restrict__ dcnt, u32 *__restrict__ dcnt_next,
+                                                                  u64 *__restrict__ walkstat) {
   __shared__ LdsTable T;
   __shared__ u32 sstat[8];
   __shared__ u32 sq[3];
   __shared__ u64 sLine[64];
   __shared__ uint2 sChr[MM_LDS_CHR];
   const u32 total = *dcnt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *dcnt_next = 0;                                        // the next batch's counter (nothing touches it during this launch)
+    if (total) atomicAdd(&walkstat[2], (u64) total);       // profiling aid: tuples passed on (mm_get_probe_stats)
+  }
   if ((size_t) blockIdx.x * 256 >= total) return;          // (uniform)
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&walkstat[2], (u64) total);   // profiling aid: tuples passed on (mm_get_probe_stats)
   if (threadIdx.x < 64) sLine[threadIdx.x] = P.lineMask[threadIdx.x];
   for (u32 c = threadIdx.x; c < min(P.nchr, (u32) MM_LDS_CHR); c += blockDim.x) sChr[c] = P.chrSlot[c];
   const uint2 *chrSlot = P.nchr <= (u32) MM_LDS_CHR ? sChr : P.chrSlot;
@@ -1171,7 +1278,7 @@ __global__ __launch_bounds__(256) MM_PROBE_ATTR void k_probe_list(const ProbePar
     }
     const bool processed = valid && !(uniqueOnly && nh != 1);
     u64 mask = 0;
-    if (processed) mask = probe_tuple<OVL>(P, true, chrSlot, sLine, a, walked);
+    if (processed) mask = probe_tuple<OVL, true>(P, true, chrSlot, sLine, a, walked);
     u32 key, pay;
     tuple_tail(grouped_strategy, ratio, false, hist ? HIST_GLOBAL : HIST_NONE, T, (u32 *) nullptr, hist, nblk, G, qlo, lane, i, a, nh, processed, mask, A, key, pay);
     if (valid && haveKey) { gkey[i] = key; gpay[i] = ratio ? nh : (pay | (min(nh, 0xFFFFu) << 16)); }
@@ -2305,7 +2412,10 @@ struct mm_index {
   // fast index (round 3): the same bins as 32-byte slots of 4-byte bin-relative records + a bitmap of the non-empty ones; NULL when the
   // bin width does not allow the encoding (see FS_* below)
   uint4 *d_fslots = nullptr;
-  u32 *d_fbits = nullptr;
+  u32 *d_fbits = nullptr;  // the map: 2 bits per fast slot
+  u32 *d_fext = nullptr;   // extension blocks (32 words each) of the bins with 8 to 31 records
+  u32 fextClass[4] = {0, 0, 0, 0};   // blocks numbered below fextClass[c] hold at most 11 / 15 / 23 / 31 records
+  u32 *d_fcls = nullptr;   // one byte per 8 fast slots: element and ok bits of the interval covering them (FS_COVERED)
   uint2 *d_fchr = nullptr; // per chromosome {first fast slot, number of fast slots}
   int fshift = 0;          // log2 of the fast slots' bin width (may be one less than sshift)
   u32 freach = 0;
@@ -2341,6 +2451,7 @@ struct mm_ctx {
   u64 *d_hm = nullptr;
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
+  int dcnt_cur = 0;
   u32 *d_dlist = nullptr, *d_dcnt = nullptr;   // tuples k_probe_fast passes on to k_probe_list: one region per wave of a tile, and the regions' lengths
   // A/B switches of the environment, read once (mm_ctx_create): MMANNOT_AMD_NO_FUSED_HIST, MMANNOT_AMD_GENERAL_PROBE, MMANNOT_AMD_FULL_INDEX_ONLY,
   // MMANNOT_AMD_NO_FAST (the round-2 walk instead of the pipelined one)
@@ -2358,8 +2469,15 @@ struct mm_ctx {
   u32 *d_bLo = nullptr, *d_bHi = nullptr, *d_bList = nullptr;   // per bucket of 4096 names: record range of the batch, and the non-empty buckets
   u64 nbcap = 0;
   // -y ratio with defer_ratio: each batch's slot-sorted (slot, NH) pairs are parked here until mm_ratio_resolve
-  struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr, *seg = nullptr; size_t n = 0; };
+  // (round 3: a parked batch keeps the buffer the sort left it in - the context takes another one from a pool for its next batch - and
+  // buffers come back to the pool when the runs are released: no allocation, no copy, no implicit device synchronisation per batch once
+  // the pool is warm; mm_ratio_reserve warms it ahead of time)
+  struct Run { u32 *k = nullptr, *v = nullptr, *info = nullptr, *seg = nullptr; size_t n = 0, cap = 0; };
   std::vector<Run> runs;
+  std::vector<Run> run_pool;          // free buffers: k = base of cap x 8 bytes (v = k + cap), then seg (2 x GT_CAP x 4), then info
+  u64 *d_xkeys = nullptr;             // staging of a table handed over from another device (mm_ratio_handoff)
+  double *d_xsums = nullptr;
+  hipEvent_t ev_handoff = nullptr;
   // optional live timing (HIP events on the context's stream), see mm_set_profiling
   int profiling = 0;   // 0 off, 1 every phase, 2 the probe phase only
   struct Span { int phase; hipEvent_t a, b; };
@@ -2367,6 +2485,7 @@ struct mm_ctx {
 };
 
 static void free_runs(mm_ctx *c);
+static void free_run_pool(mm_ctx *c);
 
 struct PhaseTimer {  // records an event pair around a group of launches when profiling is on
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
@@ -2491,7 +2610,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   std::vector<uint2> flat;
   std::vector<int> longEnd;
   std::vector<uint4> fslots;
-  std::vector<u32> fbits;
+  std::vector<u32> fbits, fcls, fext;
   std::vector<uint2> fchr;
   {
     // Bin width.  Bins holding more than 7 records leave the one-sector fast path (their list continues in `flat`),
@@ -2592,12 +2711,12 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     ix->n_slots = ns; ix->n_flat = off[ns]; ix->n_slotBits = slotBits.size();
   }
   // ---- fast slots (k_probe_fast): per bin 32 bytes = header + up to 7 records of 4 bytes, relative to the bin's first base.
-  //   header = nA | n << 4 (the first nA of the n records are intervals open at the bin's left edge), or FS_OVERFLOW
-  //   record = element:6 << 26 | ok('+' read):1 << 25 | ok('-' read):1 << 24 | payload:24
-  //   payload of an interval open at the bin's left edge = min(end - binStart, 2^24 - 1);
-  //   payload of one starting in the bin, or in the `reach` bases behind it = (start - binStart) : shift + 1 bits | min(end - start, LSAT) above.
-  // A saturated field says "at least": the kernel sends only reads to these slots that end before any saturated end could matter
-  // (read length <= fLmax = LSAT - W, start inside the chromosome's bins), so every test stays exact.  Intervals that end before the
+  //   header = number of records | number of those that are open at the bin's left edge (the first ones) << 4, or FS_OVERFLOW | extension block
+  //   record = element:6 << 26 | ok('+' read):1 << 25 | ok('-' read):1 << 24 | so : shift + 1 bits | eo above,
+  //            so = start - binStart (0 for an interval open at the bin's left edge), eo = min(end - binStart, ESAT); unused records
+  //            are zero and pass no test (neither ok bit set).
+  // A saturated eo says "at least": the kernel sends only reads to these slots that end before a saturated end could matter (read
+  // length <= fLmax = ESAT - 2 W, start inside the chromosome's bins), so every test stays exact.  Intervals that end before the
   // bin starts cannot pass for a read with end >= start and are left out; inverted zero-size intervals too (as above).  More than 7
   // records: the overflow mark (the tuple then takes the 8-byte slots above, as do reads that are too long, span more than the slot's
   // reach, have no CIGAR operations, or need the second selection pass).  The bin width is this table's own: half the width of the
@@ -2642,20 +2761,41 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       const u64 ns = count_fast(fsh, fBase, fN, cA, cI, cO);   // (the loop may have ended on a wider table than it counted last)
       const int sh = fsh;
       const u32 W = 1u << sh, reach = std::min<u32>(W, 256u);
-      const u32 lenBits = 24u - (u32) (sh + 1), LSAT = (1u << lenBits) - 1u;
-      ix->fshift = sh; ix->freach = reach; ix->fLmax = LSAT - W; ix->n_fslots = ns;
+      const u32 eoBits = 24u - (u32) (sh + 1), ESAT = (1u << eoBits) - 1u;
+      ix->fshift = sh; ix->freach = reach; ix->fLmax = ESAT - 2 * W; ix->n_fslots = ns;
       fslots.assign(ns * 2, make_uint4(0u, 0u, 0u, 0u));
-      fbits.assign((ns + 31) / 32 + 1, 0u);
+      fbits.assign((ns + 15) / 16 + 1, 0u);               // the map: 2 bits per bin (FS_EMPTY / FS_GENERAL / FS_COVERED)
+      fcls.assign(((ns + 7) / 8 + 3) / 4 + 1, 0u);        // one byte per 8 bins: the covering interval's element and ok bits
       fchr.assign(n_chromosomes, make_uint2(0u, 0u));
       for (int c = 0; c < n_chromosomes; ++c) if (seen[c]) fchr[c] = make_uint2(fBase[c], fN[c]);
-      // headers, then the records through per-bin cursors: open ones first, then those starting in the bin, then the reach - each in index order
+      // headers, then the records through per-bin cursors: open ones first, then those starting in the bin, then the reach - each in index order.
+      // A bin with 8 to FS_EXT_RECORDS records keeps them in an extension block of 128 bytes (count + records, same format), which the
+      // kernel walks for its own tile's tuples when its main loop is through; its slot only points there.
       std::vector<unsigned char> curA(ns, 0), curI(ns, 0), curO(ns, 0);
+      // (Blocks are numbered by size class - up to 11, 15, 23, 31 records = 3, 4, 6, 8 quads of 16 bytes - so that the kernel knows from
+      // a block's number how much of it to request: most overflowing bins hold 8 to 11 records.)
+      u64 n_ext = 0;
+      const bool no_ext = getenv("MMANNOT_AMD_NO_EXT") != nullptr;       // (A/B: every bin with more than 7 records goes to k_probe_list)
+      static const u32 cls_max[4] = {11u, 15u, 23u, FS_EXT_RECORDS};
+      for (int cl = 0; cl < 4; ++cl) {
+        for (u64 k = 0; k < ns && !no_ext; ++k) {
+          const u32 tot = cA[k] + cI[k] + cO[k];
+          if (tot > (cl ? cls_max[cl - 1] : 7u) && tot <= cls_max[cl] && n_ext < FS_EXT_NONE) ((u32 *) &fslots[k * 2])[0] = FS_OVERFLOW | (u32) n_ext++;
+        }
+        ix->fextClass[cl] = (u32) n_ext;                  // blocks below this number belong to class cl or a smaller one
+      }
       for (u64 k = 0; k < ns; ++k) {
         const u32 tot = cA[k] + cI[k] + cO[k];
         u32 *w = (u32 *) &fslots[k * 2];
-        if (tot > 7) w[0] = FS_OVERFLOW;
-        else { w[0] = cA[k] | (tot << 4); curI[k] = (unsigned char) cA[k]; curO[k] = (unsigned char) (cA[k] + cI[k]); }
-        if (tot) fbits[k >> 5] |= 1u << (k & 31);
+        if (tot > 7) { if (!(w[0] & FS_OVERFLOW)) w[0] = FS_OVERFLOW | FS_EXT_NONE; }
+        else w[0] = tot | (cA[k] << 4);
+        curI[k] = (unsigned char) cA[k]; curO[k] = (unsigned char) (cA[k] + cI[k]);
+        if (tot) fbits[k >> 4] |= (u32) FS_GENERAL << ((k & 15) * 2);
+      }
+      fext.assign((n_ext + 1) * 32, 0u);
+      for (u64 k = 0; k < ns; ++k) {
+        const u32 w0 = ((const u32 *) &fslots[k * 2])[0];
+        if ((w0 & FS_OVERFLOW) && (w0 & FS_EXT_NONE) != FS_EXT_NONE) fext[(size_t) (w0 & FS_EXT_NONE) * 32] = (cA[k] + cI[k] + cO[k]) | (cA[k] << 8);
       }
       for (size_t i = 0; i < n_iv; ++i) {
         if (end[i] < start[i]) continue;
@@ -2666,19 +2806,38 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
         const bool okPlus = !(eF | eR) || (eF ? ivF : !ivF), okMinus = !(eF | eR) || (eF ? !ivF : ivF);
         const u32 head = (t << 26) | ((okPlus ? 1u : 0u) << 25) | ((okMinus ? 1u : 0u) << 24);
         const u32 bs = (u32) start[i] >> sh;
-        const int64_t len = (int64_t) end[i] - (int64_t) start[i];
-        const u32 lenf = (u32) std::min<int64_t>(len, (int64_t) LSAT) << (sh + 1);
-        auto put = [&](u64 k, unsigned char &cur, u32 rec) {
-          u32 *w = (u32 *) &fslots[k * 2];
-          if (w[0] != FS_OVERFLOW) w[1 + cur++] = rec;
+        auto rec = [&](u32 b, bool open) -> u32 {            // the interval as bin b sees it
+          const int64_t binStart = (int64_t) b << sh;
+          const u32 so = open ? 0u : (u32) ((int64_t) start[i] - binStart);
+          const u32 eo = (u32) std::min<int64_t>((int64_t) end[i] - binStart, (int64_t) ESAT);
+          return head | so | (eo << (sh + 1));
         };
-        { const u64 k = (u64) fBase[c] + bs; put(k, curI[k], head | lenf | ((u32) start[i] - (bs << sh))); }
-        if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) { const u64 k = (u64) fBase[c] + bs - 1; put(k, curO[k], head | lenf | ((u32) start[i] - ((bs - 1) << sh))); }
+        auto put = [&](u64 k, unsigned char &cur, u32 r) {
+          u32 *w = (u32 *) &fslots[k * 2];
+          if (!(w[0] & FS_OVERFLOW)) w[1 + cur++] = r;
+          else if ((w[0] & FS_EXT_NONE) != FS_EXT_NONE) fext[(size_t) (w[0] & FS_EXT_NONE) * 32 + 1 + cur++] = r;
+        };
+        { const u64 k = (u64) fBase[c] + bs; put(k, curI[k], rec(bs, false)); }
+        if (bs > 0 && ((u32) start[i] & (W - 1)) < reach) { const u64 k = (u64) fBase[c] + bs - 1; put(k, curO[k], rec(bs - 1, false)); }
         const u32 b1 = std::min<u32>((u32) end[i] >> sh, fN[c] - 1);
-        for (u32 b = bs + 1; b <= b1; ++b) {
-          const u64 k = (u64) fBase[c] + b;
-          put(k, curA[k], head | (u32) std::min<int64_t>((int64_t) end[i] - ((int64_t) b << sh), 0xFFFFFF));
-        }
+        for (u32 b = bs + 1; b <= b1; ++b) { const u64 k = (u64) fBase[c] + b; put(k, curA[k], rec(b, true)); }
+      }
+      // Bins that one open interval covers from their first base to the end of their reach, and that hold nothing else: every read this
+      // table serves there lies inside that interval (its end is below binStart + 2 W), so the answer follows from the interval's element
+      // and ok bits alone - which the map keeps (code FS_COVERED + one byte per 8 bins, both small enough to stay in L2): no slot is
+      // fetched for them.  A quarter of the reads of an HS38-shaped annotation fall on such bins (long introns, gene bodies): half of its
+      // random 128-byte fetches.  Bins of one group of 8 that are covered by intervals of different elements keep their slots.
+      unsigned char *cls = (unsigned char *) fcls.data();
+      std::vector<unsigned char> have_cls((ns + 7) / 8, 0);
+      for (u64 k = 0; k < ns; ++k) {
+        const u32 *w = (const u32 *) &fslots[k * 2];
+        if (w[0] != 1u || cA[k] != 1u) continue;
+        const u32 r = w[1], eo = (r & 0xFFFFFFu) >> (sh + 1);
+        if (eo < 2 * W - 1) continue;
+        const unsigned char cl = (unsigned char) (r >> 24);
+        if (!have_cls[k >> 3]) { have_cls[k >> 3] = 1; cls[k >> 3] = cl; }
+        if (cls[k >> 3] != cl) continue;
+        fbits[k >> 4] = (fbits[k >> 4] & ~(3u << ((k & 15) * 2))) | ((u32) FS_COVERED << ((k & 15) * 2));
       }
     }
   }
@@ -2703,6 +2862,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess ||
       (!fslots.empty() && ((e = up((void **) &ix->d_fslots, fslots.data(), fslots.size() * sizeof(uint4))) != hipSuccess ||
                            (e = up((void **) &ix->d_fbits, fbits.data(), fbits.size() * sizeof(u32))) != hipSuccess ||
+                           (e = up((void **) &ix->d_fcls, fcls.data(), fcls.size() * sizeof(u32))) != hipSuccess ||
+                           (e = up((void **) &ix->d_fext, fext.data(), fext.size() * sizeof(u32))) != hipSuccess ||
                            (e = up((void **) &ix->d_fchr, fchr.data(), fchr.size() * sizeof(uint2))) != hipSuccess))) {
     mm_index_destroy(ix);
     return fail(MM_ERR_HIP, std::string("mm_index_create upload: ") + hipGetErrorString(e));
@@ -2715,7 +2876,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
-  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fchr);
+  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fcls); (void) hipFree(ix->d_fext); (void) hipFree(ix->d_fchr);
   delete ix;
 }
 
@@ -2777,6 +2938,9 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   (void) hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
   free_runs(c);
+  free_run_pool(c);
+  (void) hipFree(c->d_xkeys); (void) hipFree(c->d_xsums);
+  if (c->ev_handoff) (void) hipEventDestroy(c->ev_handoff);
   ctx_free_batch(c);
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
@@ -2824,10 +2988,11 @@ static int ensure_batch(mm_ctx *c, size_t n, bool need_copy) {
     const size_t nblk = (cap + RS_TILE - 1) / RS_TILE;
     HIPCHK(hipMalloc((void **) &c->d_hm, cap * 8)); HIPCHK(hipMalloc((void **) &c->d_gkey, cap * 4)); HIPCHK(hipMalloc((void **) &c->d_gpay, cap * 4));
     // (keys and payloads of one buffer are the two halves of one allocation: the leaf layout's partition pass writes 8-byte pairs there)
-    HIPCHK(hipMalloc((void **) &c->d_kA, cap * 8)); c->d_vA = c->d_kA + cap;
+    HIPCHK(hipMalloc((void **) &c->d_kA, cap * 8 + 2 * GT_CAP * 4 + 64)); c->d_vA = c->d_kA + cap;   // (laid out like a parked batch's buffer: -y ratio with defer_ratio hands it over)
+    free_run_pool(c);                                       // (buffers of the old capacity)
     HIPCHK(hipMalloc((void **) &c->d_kB, cap * 8)); c->d_vB = c->d_kB + cap;
     HIPCHK(hipMalloc((void **) &c->d_hist, (size_t) RS_ROWS * nblk * 4));
-    HIPCHK(hipMalloc((void **) &c->d_dlist, 2 * nblk * (size_t) RS_TILE * 4)); HIPCHK(hipMalloc((void **) &c->d_dcnt, 16));
+    HIPCHK(hipMalloc((void **) &c->d_dlist, 2 * nblk * (size_t) RS_TILE * 4)); HIPCHK(hipMalloc((void **) &c->d_dcnt, 16)); HIPCHK(hipMemsetAsync(c->d_dcnt, 0, 16, c->stream));
     HIPCHK(hipMalloc((void **) &c->d_tileTot, 2 * (cap / RATIO_CHUNK + 2) * 8)); HIPCHK(hipMalloc((void **) &c->d_tileK, 2 * (cap / RATIO_CHUNK + 2) * 4));
     c->cap = cap;
   }
@@ -2867,7 +3032,7 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   const mm_index *ix = c->ix;
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
-  P.fslots = ix->d_fslots; P.fbits = ix->d_fbits; P.fchr = ix->d_fchr; P.fLmax = ix->fLmax; P.fshift = (u32) ix->fshift; P.freach = ix->freach;
+  P.fslots = ix->d_fslots; P.fbits = ix->d_fbits; P.fcls = ix->d_fcls; P.fext = (const uint4 *) ix->d_fext; P.fextClass[0] = ix->fextClass[0]; P.fextClass[1] = ix->fextClass[1]; P.fextClass[2] = ix->fextClass[2]; P.fchr = ix->d_fchr; P.fLmax = ix->fLmax; P.fshift = (u32) ix->fshift; P.freach = ix->freach;
   P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
   P.useSlots = c->env_full_index_only ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
@@ -2914,9 +3079,13 @@ static int sort_pairs(mm_ctx *c, size_t n, int passes, int fixed_bits, int rebas
   return MM_OK;
 }
 
-__global__ __launch_bounds__(256) void k_seed_rows(const u64 *__restrict__ masks, const double *__restrict__ sums, u32 n, GlobalTable G) {
+__device__ __forceinline__ u32 row_chunk_of(u64 mask, u32 n_chunks) { return n_chunks <= 1 ? 0u : (u32) ((mask * 0x9E3779B97F4A7C15ull) >> 40) % n_chunks; }
+// rows (element set, bit pattern of its sum) of another context -> this one's table; empty entries (set 0) and, with n_chunks > 1, the rows
+// of other chunks are skipped
+__global__ __launch_bounds__(256) void k_seed_rows(const u64 *__restrict__ masks, const double *__restrict__ sums, u32 n, GlobalTable G, u32 chunk, u32 n_chunks) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || masks[i] == 0) return;
+  if (n_chunks > 1 && row_chunk_of(masks[i], n_chunks) != chunk) return;
   const u32 s = gt_find_or_insert(G, masks[i]);
   if (s != NO_KEY) G.sum[s] = sums[i];
 }
@@ -2942,9 +3111,21 @@ static int ratio_accumulate(mm_ctx *c, const u32 *keys, const u32 *vals, const u
   return MM_OK;
 }
 
-static void free_runs(mm_ctx *c) {
-  for (auto &r : c->runs) { (void) hipFree(r.k); (void) hipFree(r.v); (void) hipFree(r.info); (void) hipFree(r.seg); }
+// a buffer for one parked batch of up to `cap` pairs: from the pool, or a new allocation (keys | values | segment bounds | batch scalars)
+static int take_run_buffer(mm_ctx *c, size_t cap, mm_ctx::Run &r) {
+  for (size_t k = 0; k < c->run_pool.size(); ++k) if (c->run_pool[k].cap >= cap) { r = c->run_pool[k]; c->run_pool.erase(c->run_pool.begin() + (long) k); r.n = 0; return MM_OK; }
+  u32 *base = nullptr;
+  HIPCHK(hipMalloc((void **) &base, cap * 8 + 2 * GT_CAP * 4 + 64));
+  r.k = base; r.v = base + cap; r.seg = base + 2 * cap; r.info = r.seg + 2 * GT_CAP; r.cap = cap; r.n = 0;
+  return MM_OK;
+}
+static void free_runs(mm_ctx *c) {       // parked batches -> their buffers back to the pool (the caller has synchronised the stream)
+  for (auto &r : c->runs) c->run_pool.push_back(r);
   c->runs.clear();
+}
+static void free_run_pool(mm_ctx *c) {
+  for (auto &r : c->run_pool) (void) hipFree(r.k);
+  c->run_pool.clear();
 }
 
 // the batch's (index, NH) side list -> device, through one of two pinned staging sets (the caller's array is free on return)
@@ -3053,10 +3234,12 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   const bool fast = var != PV_GENERAL && P.fslots != nullptr && !c->env_no_fast;
   if (fast) {
     u32 *const dlist2 = c->d_dlist + (size_t) nblk * RS_TILE;        // the compacted list (the first half: the waves' regions)
-    HIPCHK(hipMemsetAsync(c->d_dcnt, 0, 4, c->stream));
+    // the list's length: two counters used in turn - k_probe_list zeroes the other one for the next batch (no memset launch per batch)
+    u32 *const dcnt = c->d_dcnt + c->dcnt_cur, *const dcnt_next = c->d_dcnt + (c->dcnt_cur ^ 1);
+    c->dcnt_cur ^= 1;
 #define MM_LAUNCH_FAST(OVL, VAR)                                                                                                     \
   hipLaunchKernelGGL((k_probe_fast<OVL, VAR>), dim3(nblk), dim3(256), 0, c->stream, P, d_aln, single ? 1 : 0,                         \
-                     (u32) qid_lo, n, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk, c->d_dlist, dlist2, c->d_dcnt)
+                     (u32) qid_lo, n, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk, c->d_dlist, dlist2, dcnt)
 #define MM_LAUNCH_FAST_VAR(OVL)                                       \
   switch (var) {                                                      \
     case PV_COUNT: MM_LAUNCH_FAST(OVL, PV_COUNT); break;              \
@@ -3068,7 +3251,7 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
 #define MM_LAUNCH_LIST(OVL)                                                                                                          \
   hipLaunchKernelGGL((k_probe_list<OVL>), dim3(std::min<u32>(2048u, (u32) ((n + 255) / 256))), dim3(256), 0, c->stream, P, d_aln, d_big, (u32) n_big, \
                      single ? 1 : 0, (u32) qid_lo, gkey, c->d_gpay, c->d_M, c->G, c->d_stats, fuse_hist ? c->d_hist : (u32 *) nullptr, nblk, \
-                     (const u32 *) dlist2, (const u32 *) c->d_dcnt, c->d_walk)
+                     (const u32 *) dlist2, (const u32 *) dcnt, dcnt_next, c->d_walk)
     switch (c->opt.overlap_mode) {
       case MM_OVL_INCLUSION: MM_LAUNCH_FAST_VAR(MM_OVL_INCLUSION) MM_LAUNCH_LIST(MM_OVL_INCLUSION); break;
       case MM_OVL_PC: MM_LAUNCH_FAST_VAR(MM_OVL_PC) MM_LAUNCH_LIST(MM_OVL_PC); break;
@@ -3137,16 +3320,16 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
       if (!force_leaf)
       hipLaunchKernelGGL(k_chunk_default, dim3(grid), dim3(256), 0, c->stream, c->d_kA, c->d_vA, c->d_kB, c->d_vB, c->d_M, d_aln, d_big, (u32) n_big, hm,
                          c->d_grpRem, c->d_grpU, c->qcap, c->G, c->d_stats, c->ix->E);
-    } else if (c->opt.defer_ratio) {  // 16 key bits = two passes: the sorted pairs are back in A; park them
+    } else if (c->opt.defer_ratio) {  // the sorted pairs are in A: park them - the run keeps A, the context goes on with a buffer from the pool
+      mm_ctx::Run fresh;
+      rc = take_run_buffer(c, c->cap, fresh);
+      if (rc) return rc;
       mm_ctx::Run r;
-      r.n = n;
-      HIPCHK(hipMalloc((void **) &r.k, n * 4)); HIPCHK(hipMalloc((void **) &r.v, n * 4)); HIPCHK(hipMalloc((void **) &r.info, INFO_WORDS * 4));
-      HIPCHK(hipMemcpyAsync(r.k, c->d_kA, n * 4, hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(hipMemcpyAsync(r.v, c->d_vA, n * 4, hipMemcpyDeviceToDevice, c->stream));
+      r.k = c->d_kA; r.v = c->d_vA; r.seg = c->d_kA + 2 * c->cap; r.info = r.seg + 2 * GT_CAP; r.cap = c->cap; r.n = n;
+      c->d_kA = fresh.k; c->d_vA = fresh.v;
       HIPCHK(hipMemcpyAsync(r.info, c->d_M, INFO_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(hipMalloc((void **) &r.seg, 2 * GT_CAP * 4));       // every slot's segment of this batch: known now, off the chain's critical path
       c->runs.push_back(r);
-      rc = ratio_bounds(c, r.k, r.info, n, r.seg);
+      rc = ratio_bounds(c, r.k, r.info, n, r.seg);        // every slot's segment of this batch: known now, off the chain's critical path
       if (rc) return rc;
     } else {
       rc = ratio_accumulate(c, c->d_kA, c->d_vA, c->d_M, n);
@@ -3212,7 +3395,7 @@ extern "C" int mm_set_row_sums(mm_ctx *c, const uint64_t *masks, const double *s
   HIPCHK(hipMalloc((void **) &dm, n * 8)); HIPCHK(hipMalloc((void **) &ds, n * 8));
   HIPCHK(hipMemcpyAsync(dm, masks, n * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(ds, sums, n * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_seed_rows, dim3((u32) ((n + 255) / 256)), dim3(256), 0, c->stream, dm, ds, (u32) n, c->G);
+  hipLaunchKernelGGL(k_seed_rows, dim3((u32) ((n + 255) / 256)), dim3(256), 0, c->stream, dm, ds, (u32) n, c->G, 0u, 1u);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void) hipFree(dm); (void) hipFree(ds);
@@ -3234,7 +3417,7 @@ extern "C" int mm_ratio_resolve_n(mm_ctx *c, size_t max_runs) {
     ++done;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (size_t k = 0; k < done; ++k) { (void) hipFree(c->runs[k].k); (void) hipFree(c->runs[k].v); (void) hipFree(c->runs[k].info); (void) hipFree(c->runs[k].seg); }
+  for (size_t k = 0; k < done; ++k) c->run_pool.push_back(c->runs[k]);
   c->runs.erase(c->runs.begin(), c->runs.begin() + (long) done);
   return check_table(c);
 }
@@ -3254,6 +3437,75 @@ extern "C" int mm_ratio_resolve_chunk(mm_ctx *c, uint32_t chunk, uint32_t n_chun
   HIPCHK(hipStreamSynchronize(c->stream));
   if (chunk + 1 == n_chunks) free_runs(c);
   return check_table(c);
+}
+// ---- the -y ratio chain without host hops (round 3).  The whole table travels: MM_TABLE_SLOTS element sets and the bit patterns of their
+// sums, empty slots with set 0 - 1 MB, fixed size, so neither side has to know how many rows there are; everything is asynchronous on
+// the context's stream.
+extern "C" int mm_table_export_device(mm_ctx *c, uint64_t *d_keys, double *d_sums) {
+  if (!c || !d_keys || !d_sums) return fail(MM_ERR_ARG, "mm_table_export_device: null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipMemcpyAsync(d_keys, c->G.key, GT_CAP * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_sums, c->G.sum, GT_CAP * 8, hipMemcpyDeviceToDevice, c->stream));
+  return MM_OK;
+}
+extern "C" int mm_table_import_device(mm_ctx *c, const uint64_t *d_keys, const double *d_sums, size_t n, uint32_t chunk, uint32_t n_chunks) {
+  if (!c || (n && (!d_keys || !d_sums)) || n_chunks == 0 || chunk >= n_chunks) return fail(MM_ERR_ARG, "mm_table_import_device: bad argument");
+  if (c->opt.strategy != MM_STRAT_RATIO) return fail(MM_ERR_STATE, "mm_table_import_device: only meaningful under -y ratio");
+  if (n == 0) return MM_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipLaunchKernelGGL(k_seed_rows, dim3((u32) ((n + 255) / 256)), dim3(256), 0, c->stream, (const u64 *) d_keys, d_sums, (u32) n, c->G, chunk, n_chunks);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+// replays parked batches [first, first + count) for the rows of one chunk, asynchronously; nothing is released (mm_ratio_release)
+extern "C" int mm_ratio_replay(mm_ctx *c, size_t first, size_t count, uint32_t chunk, uint32_t n_chunks) {
+  if (!c || n_chunks == 0 || chunk >= n_chunks) return fail(MM_ERR_ARG, "mm_ratio_replay: bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  for (size_t k = first; k < c->runs.size() && k - first < count; ++k) {
+    PhaseTimer t(c, MM_PHASE_MERGE);
+    const mm_ctx::Run &r = c->runs[k];
+    const int rc = ratio_accumulate(c, r.k, r.v, r.info, r.n, r.seg, chunk, n_chunks);
+    if (rc) return rc;
+  }
+  return MM_OK;
+}
+extern "C" int mm_ratio_release(mm_ctx *c) {
+  if (!c) return fail(MM_ERR_ARG, "mm_ratio_release: null context");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  free_runs(c);
+  return check_table(c);
+}
+// buffers for n_runs parked batches of up to batch_capacity tuples, allocated now instead of in the middle of a stream
+extern "C" int mm_ratio_reserve(mm_ctx *c, size_t n_runs, size_t batch_capacity) {
+  if (!c) return fail(MM_ERR_ARG, "mm_ratio_reserve: null context");
+  if (c->opt.strategy != MM_STRAT_RATIO || !c->opt.defer_ratio) return MM_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  int rc = ensure_batch(c, std::max<size_t>(batch_capacity, 1), false);
+  if (rc) return rc;
+  std::vector<mm_ctx::Run> got;
+  for (size_t k = 0; k < n_runs; ++k) { mm_ctx::Run r; rc = take_run_buffer(c, c->cap, r); if (rc) break; got.push_back(r); }
+  for (auto &r : got) c->run_pool.push_back(r);
+  return rc;
+}
+// the table of src (any device) -> dst's rows of one chunk, ordered behind everything src's stream holds so far and ahead of what dst's
+// stream gets next; asynchronous
+extern "C" int mm_ratio_handoff(mm_ctx *src, mm_ctx *dst, uint32_t chunk, uint32_t n_chunks) {
+  if (!src || !dst || src == dst) return fail(MM_ERR_ARG, "mm_ratio_handoff: bad argument");
+  HIPCHK(hipSetDevice(src->ix->device));
+  if (!src->ev_handoff) HIPCHK(hipEventCreateWithFlags(&src->ev_handoff, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(src->ev_handoff, src->stream));
+  HIPCHK(hipSetDevice(dst->ix->device));
+  if (!dst->d_xkeys) { HIPCHK(hipMalloc((void **) &dst->d_xkeys, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &dst->d_xsums, GT_CAP * 8)); }
+  HIPCHK(hipStreamWaitEvent(dst->stream, src->ev_handoff, 0));
+  if (src->ix->device == dst->ix->device) {
+    HIPCHK(hipMemcpyAsync(dst->d_xkeys, src->G.key, GT_CAP * 8, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->d_xsums, src->G.sum, GT_CAP * 8, hipMemcpyDeviceToDevice, dst->stream));
+  } else {
+    HIPCHK(hipMemcpyPeerAsync(dst->d_xkeys, dst->ix->device, src->G.key, src->ix->device, GT_CAP * 8, dst->stream));
+    HIPCHK(hipMemcpyPeerAsync(dst->d_xsums, dst->ix->device, src->G.sum, src->ix->device, GT_CAP * 8, dst->stream));
+  }
+  return mm_table_import_device(dst, (const uint64_t *) dst->d_xkeys, dst->d_xsums, GT_CAP, chunk, n_chunks);
 }
 /* chunk of a row, for callers that split mm_get_rows by chunk */
 extern "C" uint32_t mm_row_chunk(uint64_t mask, uint32_t n_chunks) { return n_chunks <= 1 ? 0u : (uint32_t) ((mask * 0x9E3779B97F4A7C15ull) >> 40) % n_chunks; }

@@ -259,23 +259,29 @@ extern "C" int mm_merge(mm_ctx *const *ctxs, int n_ctx, int strategy, uint64_t *
     return rc;
   };
   if (strategy == MM_STRAT_RATIO && n_ctx > 1) {
-    // batch j of the input went to ctxs[j % n_ctx]: replay the parked accumulations in that order, each one starting from the
-    // sums its predecessor ended with
-    bool first = true;
+    // batch j of the input went to ctxs[j % n_ctx]: replay the parked accumulations in that order, each one starting from the sums its
+    // predecessor ended with.  Round 3: the table goes from context to context on the devices (mm_ratio_handoff: a peer copy ordered by
+    // events on both streams) and nothing waits for the host until the last batch is enqueued - one mm_get_rows / mm_set_row_sums round
+    // trip per batch before.
+    std::vector<size_t> cursor((size_t) n_ctx, 0);
+    mm_ctx *prev = nullptr;
     for (size_t j = 0;; ++j) {
-      mm_ctx *c = ctxs[j % (size_t) n_ctx];
-      if (mm_ratio_pending(c) == 0) break;
-      if (!first && !m.empty()) { const int rc = mm_set_row_sums(c, m.data(), v.data(), m.size()); if (rc) return rc; }
-      int rc = mm_ratio_resolve_n(c, 1);
+      const size_t k = j % (size_t) n_ctx;
+      mm_ctx *c = ctxs[k];
+      if (cursor[k] >= mm_ratio_pending(c)) break;
+      if (prev) { const int rc = mm_ratio_handoff(prev, c, 0, 1); if (rc) return rc; }
+      const int rc = mm_ratio_replay(c, cursor[k]++, 1, 0, 1);
       if (rc) return rc;
-      rc = rows_of(c);
-      if (rc) return rc;
-      first = false;
+      prev = c;
     }
-    for (int k = 0; k < n_ctx; ++k) if (mm_ratio_pending(ctxs[k]) != 0) return MM_ERR_STATE;   // batches were not dealt round-robin from ctxs[0]
-    if (first) { const int rc = rows_of(ctxs[0]); if (rc) return rc; }   // nothing parked (any more): every context holds the final rows
-    else for (int k = 0; k < n_ctx; ++k) {   // leave the input's final sums in every context (a second call - sizes first, rows then - finds them)
-      const int rc = m.empty() ? MM_OK : mm_set_row_sums(ctxs[k], m.data(), v.data(), m.size());
+    for (int k = 0; k < n_ctx; ++k) if (cursor[(size_t) k] != mm_ratio_pending(ctxs[k])) return MM_ERR_STATE;   // batches were not dealt round-robin from ctxs[0]
+    for (int k = 0; k < n_ctx; ++k) { const int rc = mm_ratio_release(ctxs[k]); if (rc) return rc; }
+    if (!prev) { const int rc = rows_of(ctxs[0]); if (rc) return rc; }   // nothing parked (any more): every context holds the final rows
+    else {
+      // leave the input's final sums in every context (a second call - sizes first, rows then - finds them)
+      for (int k = 0; k < n_ctx; ++k) if (ctxs[k] != prev) { const int rc = mm_ratio_handoff(prev, ctxs[k], 0, 1); if (rc) return rc; }
+      for (int k = 0; k < n_ctx; ++k) { const int rc = mm_sync(ctxs[k]); if (rc) return rc; }
+      const int rc = rows_of(prev);
       if (rc) return rc;
     }
   } else if (n_ctx == 1) {

@@ -84,8 +84,10 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunk
     the chunk's rows, replays its parked batches for those rows only (mm_ratio_resolve_chunk) and sends them on - the next rank
     works on chunk c while this one goes on with c+1, (ranks + n_chunks - 1) / n_chunks replays instead of `ranks`.  Measured
     (DESIGN.md section 5): with rows travelling through the host on every hop the fixed cost per hop outweighs the overlap, so
-    the default stays 1.  Returns (masks, sums, stats) identical on every rank."""
+    the default stays 1 there.  With device tensors (backend nccl = RCCL) the table stays on the devices (mm_table_export_device /
+    mm_table_import_device / mm_ratio_replay, no host hop) and chunking pays.  Returns (masks, sums, stats) identical on every rank."""
     from .api import row_chunk
+    chain_ratio.last_hop_ms = None
     if _alone(group):
         counter.resolve_ratio()
         m, s = counter.getCounts()
@@ -110,15 +112,38 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunk
         return m.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.float64)
 
     n_chunks = max(1, int(n_chunks))
-    for c in range(n_chunks):
-        if rank > 0:
-            m, s = recv_rows(rank - 1)
-            counter.set_row_sums(m, s)
-        counter.resolve_ratio_chunk(c, n_chunks)
-        if rank < ws - 1:
-            masks, sums = counter.getCounts()
-            sel = row_chunk(masks, n_chunks) == c
-            send_rows(np.ascontiguousarray(masks[sel]), np.ascontiguousarray(sums[sel]), rank + 1)
+    if dev.type == "cuda":
+        # Round 3: the table never leaves the devices.  What travels is the whole table - 65,536 element sets and the bit patterns of
+        # their sums, 1 MB, fixed size, so no count has to be exchanged first - from the context's stream into a tensor, over RCCL
+        # (send / recv are ordered against that stream) and from the tensor into the next context's rows; nothing waits for the host
+        # until the chain's last replay is enqueued.  Rows are independent of each other, so the chain is pipelined by row chunks: a
+        # rank works on chunk c + 1 while the next one replays chunk c.
+        S = counter.TABLE_SLOTS
+        bufs = [torch.zeros(2 * S, dtype=torch.int64, device=dev) for _ in range(2)]       # (a send may still be reading the previous chunk's)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_chunks)]
+        for c in range(n_chunks):
+            buf = bufs[c & 1]
+            ev[c][0].record()
+            if rank > 0:
+                dist.recv(buf, src=rank - 1, group=group)
+                counter.import_table_device(buf.data_ptr(), buf.data_ptr() + 8 * S, S, c, n_chunks)
+            counter.ratio_replay(0, 1 << 62, c, n_chunks)
+            if rank < ws - 1:
+                counter.export_table_device(buf.data_ptr(), buf.data_ptr() + 8 * S)
+                dist.send(buf, dst=rank + 1, group=group)
+            ev[c][1].record()
+        counter.ratio_release()
+        chain_ratio.last_hop_ms = [a.elapsed_time(b) for a, b in ev]      # per chunk on this rank: wait for the predecessor + replay + hand-over
+    else:
+        for c in range(n_chunks):
+            if rank > 0:
+                m, s = recv_rows(rank - 1)
+                counter.set_row_sums(m, s)
+            counter.resolve_ratio_chunk(c, n_chunks)
+            if rank < ws - 1:
+                masks, sums = counter.getCounts()
+                sel = row_chunk(masks, n_chunks) == c
+                send_rows(np.ascontiguousarray(masks[sel]), np.ascontiguousarray(sums[sel]), rank + 1)
     masks, sums = counter.getCounts()
     # final table from the last rank to everybody
     n = torch.tensor([len(masks)], dtype=torch.int64, device=dev)

@@ -113,10 +113,12 @@ def _elem_id(cfg, source, typ):
 
 
 def synth_annotation(shape: str = "hs38", seed: int = 3, scale: float = 1.0, up: int = 1000, down: int = 1000,
-                     keep_genes: bool = False) -> Annotation:
+                     keep_genes: bool = False, scaffolds: int = 0) -> Annotation:
+    """scaffolds > 0: that many unplaced scaffolds of 60 kb behind the chromosomes (an assembly with its unlocalised sequences: hundreds to
+    thousands of reference names), genes placed on them at the same density."""
     rng = np.random.default_rng(seed)
     cfg = config_json(shape)
-    chrs = {"hs38": HS38_CHR, "tair10": TAIR10_CHR, "flybase6": FLY_CHR}[shape]
+    chrs = list({"hs38": HS38_CHR, "tair10": TAIR10_CHR, "flybase6": FLY_CHR}[shape]) + [(f"scaffold_{k}", 0.06) for k in range(scaffolds)]
     names = [c for c, _ in chrs]
     clen = np.array([int(m * 1e6) for _, m in chrs], dtype=np.int64)
     total = clen.sum()

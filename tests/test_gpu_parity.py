@@ -336,7 +336,7 @@ def test_qid_bound_too_small_is_an_error_not_a_fault(gpu_lib):
     ctr.close(); index.close()
 
 
-@pytest.mark.parametrize("chunks", [1, 5])
+@pytest.mark.parametrize("chunks", [1, 5, "handoff", "handoff5", "device_tensors", "interleaved"])
 def test_ratio_chain_across_contexts(gpu_lib, oracle, chunks):
     """Multi-GPU -y ratio in miniature: two contexts hold consecutive blocks of one stream, park their accumulation
     (defer_ratio) and chain the per-row sums; the result must be bit-identical to one context over the whole stream and to
@@ -363,7 +363,36 @@ def test_ratio_chain_across_contexts(gpu_lib, oracle, chunks):
     for lo, hi in ((cut, 1_700_000), (1_700_000, n)):
         b.add_batch(aln[lo:hi], t["nh"][lo:hi], n); b.sync()
     a.flush(); b.flush()
-    if chunks == 1:
+    if chunks == "interleaved":   # mm_merge's order for batches dealt round-robin (a0 b0 a1 b1): tables handed over per batch, all on the devices
+        a.close(); b.close()
+        a = mm.Counter(index, strategy="ratio", defer_ratio=True); b = mm.Counter(index, strategy="ratio", defer_ratio=True)
+        a.ratio_reserve(2, 800_000); b.ratio_reserve(2, 800_000)                # (buffers for the parked batches ahead of time)
+        cuts = (0, 400_000, cut, 1_700_000, n)
+        for k, ctr in enumerate((a, b, a, b)):
+            ctr.add_batch(aln[cuts[k]:cuts[k + 1]], t["nh"][cuts[k]:cuts[k + 1]], n)
+        a.sync(); b.sync()
+        assert a.ratio_pending() == 2 and b.ratio_pending() == 2
+        a.ratio_replay(0, 1); a.ratio_handoff_to(b); b.ratio_replay(0, 1); b.ratio_handoff_to(a)
+        a.ratio_replay(1, 1); a.ratio_handoff_to(b); b.ratio_replay(1, 1)
+        a.ratio_release(); b.ratio_release()
+        assert a.ratio_pending() == 0 and b.ratio_pending() == 0
+    elif chunks in ("handoff", "handoff5"):   # the chain without a host hop: mm_ratio_replay + mm_ratio_handoff (a peer copy between devices; here one device)
+        nc = 5 if chunks == "handoff5" else 1
+        for c in range(nc):
+            a.ratio_replay(0, 1 << 40, c, nc)
+            a.ratio_handoff_to(b, c, nc)
+            b.ratio_replay(0, 1 << 40, c, nc)
+        a.ratio_release(); b.ratio_release()
+    elif chunks == "device_tensors":          # ... and through a buffer of the caller's (what dist.chain_ratio sends over RCCL)
+        import torch
+        buf = torch.zeros(2 * mm.Counter.TABLE_SLOTS, dtype=torch.int64, device="cuda")
+        a.ratio_replay()
+        a.export_table_device(buf.data_ptr(), buf.data_ptr() + 8 * mm.Counter.TABLE_SLOTS)
+        a.sync()
+        b.import_table_device(buf.data_ptr(), buf.data_ptr() + 8 * mm.Counter.TABLE_SLOTS)
+        b.ratio_replay()
+        a.ratio_release(); b.ratio_release()
+    elif chunks == 1:
         a.resolve_ratio()
         ma, sa = a.getCounts()
         b.set_row_sums(ma, sa)

@@ -182,3 +182,56 @@ def test_sixty_five_order_elements_are_refused(gpu_lib):
     assert b"64" in _lib.lib().mm_last_error()
     with pytest.raises(ValueError):
         mm.Config([mm.ConfigElement("s", f"t{e}", 0, e) for e in range(65)])
+
+
+def _clustered_index(rng, desc, nchr=3, maxpos=400_000):
+    """Bins of every kind the pipelined probe (k_probe_fast) distinguishes: empty stretches; stretches covered by one long interval and
+    nothing else (answered from the map's class byte, no slot fetched); ordinary bins (<= 7 records: the 32-byte slot); clusters of
+    8-11 / 12-15 / 16-23 / 24-31 intervals within 100 bases (extension blocks of every size class, walked at the end of the tile);
+    clusters of 40 and 70 (handed to k_probe_list); and, through them, "upstream" / "downstream" elements (the selection pass)."""
+    E = desc.E
+    chr_, start, end, typ, strand = [], [], [], [], []
+
+    def add(c, s, e, t=None):
+        chr_.append(c); start.append(int(s)); end.append(int(e)); typ.append(int(rng.integers(0, E)) if t is None else t); strand.append(int(rng.integers(1, 3)))
+    for c in range(nchr):
+        pos = 5000
+        while pos < maxpos - 40_000:
+            kind = int(rng.integers(0, 8))
+            if kind == 0:                                  # one long interval over an otherwise empty stretch
+                add(c, pos, pos + int(rng.integers(3000, 30_000)))
+                pos = end[-1] + int(rng.integers(2000, 6000))
+            elif kind in (1, 2, 3):                        # sparse ordinary intervals
+                for _ in range(int(rng.integers(1, 6))):
+                    s = pos + int(rng.integers(0, 2000)); add(c, s, s + int(rng.integers(20, 900)))
+                pos += int(rng.integers(2500, 5000))
+            else:                                          # a cluster: n intervals starting within 100 bases, mixed lengths
+                n = int(rng.choice([9, 11, 13, 15, 18, 23, 27, 31, 40, 70]))
+                for _ in range(n):
+                    s = pos + int(rng.integers(0, 100)); add(c, s, s + int(rng.integers(30, 2500)))
+                pos += int(rng.integers(3000, 6000))
+    return _sorted_index(np.array(chr_), np.array(start), np.array(end), np.array(typ), np.array(strand), nchr)
+
+
+@pytest.mark.parametrize("strategy,l,s", [("default", -1.0, "F"), ("default", 0.3, "U"), ("default", 20.0, "R"), ("ratio", -1.0, "F"), ("ratio", 20.0, "U"),
+                                          ("unique", -1.0, "F"), ("unique", 0.3, "R")])
+def test_every_kind_of_bin_of_the_pipelined_probe(gpu_lib, oracle, strategy, l, s):
+    mm = gpu_lib
+    rng = np.random.default_rng(77)
+    desc = sr.random_config(rng, n_lines=6, max_per_line=3)
+    ix = _clustered_index(rng, desc)
+    # four tiles and a partial one (a tile is 8192 tuples), reads of 20-120 bases (2 % up to 40 kb), 3 % without CIGAR operations, groups of
+    # every shape; half of the reads land within 60 bases of an interval boundary
+    reads = sr.random_reads(rng, ix, n=4 * 8192 + 1234, nchr=3, maxpos=400_000, nh_max=6)
+    ref = check(mm, oracle, desc, ix, reads, overlap=l, strandedness=s, strategy=strategy, shifts=(0, 9, 11), batches=(1, 2, 3))
+    # and the instance compiled for the launch really took the pipelined kernel, answering nearly all of it
+    cfg = to_cfg(mm, desc)
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], ix["n_chromosomes"])
+    ctr = mm.Counter(index, overlap=l, strandedness=s, strategy=strategy)
+    aln = mm.pack_alignments(reads["tid"], reads["start"], reads["end"], reads["strand"], reads["qid"])
+    ctr.add_batch(aln, reads["nh"].astype(np.uint32), int(reads["qid"].max()) + 1)
+    ctr.flush()
+    ps = ctr.probe_stats()
+    assert ctr.stats() == ref.stats
+    assert ps["fast_slot_bytes"] > 0 and 0 < ps["passed_on"] < 0.5 * len(aln), ps
+    ctr.close(); index.close()

@@ -15,6 +15,10 @@ extern "C" int mm_get_stats(mm_ctx *, uint64_t *) { return MM_ERR_HIP; }
 extern "C" int mm_get_rows(mm_ctx *, uint64_t *, double *, size_t, size_t *) { return MM_ERR_HIP; }
 extern "C" int mm_set_row_sums(mm_ctx *, const uint64_t *, const double *, size_t) { return MM_ERR_HIP; }
 extern "C" int mm_ratio_resolve_n(mm_ctx *, size_t) { return MM_ERR_HIP; }
+extern "C" int mm_ratio_handoff(mm_ctx *, mm_ctx *, uint32_t, uint32_t) { return MM_ERR_HIP; }
+extern "C" int mm_ratio_replay(mm_ctx *, size_t, size_t, uint32_t, uint32_t) { return MM_ERR_HIP; }
+extern "C" int mm_ratio_release(mm_ctx *) { return MM_ERR_HIP; }
+extern "C" int mm_sync(mm_ctx *) { return MM_ERR_HIP; }
 extern "C" size_t mm_ratio_pending(const mm_ctx *) { return 0; }
 extern "C" uint32_t mm_row_chunk(uint64_t mask, uint32_t n) { return n <= 1 ? 0u : (uint32_t) ((mask * 0x9E3779B97F4A7C15ull) >> 40) % n; }
 EOS
