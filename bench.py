@@ -318,6 +318,7 @@ def main():
                 raise
     res_dev = run_leg(False) if args.legs in ("both", "resident") else None
     probe_stats = ctr.probe_stats() if res_dev is not None else None       # (of the resident leg: warm-up + timed batches)
+    probe_path = ctr.probe_path()          # the context has measured its two probes on its first batches and kept the faster one
     if res_host is not None and res_pk is not None:
         oh, op = np.argsort(res_host[2]), np.argsort(res_pk[2])
         assert res_host[4] == res_pk[4] and np.array_equal(res_host[2][oh], res_pk[2][op])
@@ -418,10 +419,11 @@ def main():
                                   "note": "same batches resident in HBM when the timed region starts (no copy); the roofline leg",
                                   "step_roofline": {"bound": "hbm", "alg_bytes_per_alignment": b_step, "achieved": step_gbs, "peak": 8000.0,
                                                     "unit": "GB/s", "frac": step_gbs / 8000.0}}
-            out["roofline"] = {"bound": "hbm", "kernel": "k_probe", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            out["roofline"] = {"bound": "hbm", "kernel": {"pipelined": "k_probe_fast + k_probe_list", "walk": "k_probe"}.get(probe_path, "k_probe / k_probe_fast (undecided)"),
+                               "probe_path": probe_path, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_alignment": B_ALG_PROBE,
                                "avg_launch_ms": avg_probe_s * 1e3, "dominant_phase": dom,
-                               # the probe phase = k_probe_fast (pipelined walk over 32-byte slots) + k_probe_list (the tuples it hands on)
+                               # (pipelined: the probe phase = k_probe_fast, the walk over 32-byte slots, + k_probe_list, the tuples it hands on)
                                "passed_on_frac": probe_stats["passed_on"] / max(1, sum(sizes)), "fast_slot_bytes": probe_stats["fast_slot_bytes"]}
             if traffic and B == (1 << 24):     # (the counters were collected on 2^24-tuple launches) the same kernel in the bytes that really moved
                 out["roofline"]["traffic_achieved"] = traffic / avg_probe_s / 1e9

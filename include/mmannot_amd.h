@@ -196,6 +196,11 @@ int mm_get_walk_stats(mm_ctx *ctx, uint64_t out[2]);
  * allow or without CIGAR operations, NH values from the side list, hits that need the max-overlap / min-distance selection
  * (mmannot.cpp:1049-1075); out[3]: bytes of the fast slot table (0: the index has none). */
 int mm_get_probe_stats(mm_ctx *ctx, uint64_t out[4]);
+/* Which probe the context runs where both apply (no side outputs, at most 256 chromosomes): 1 = the pipelined one (k_probe_fast +
+ * k_probe_list), 2 = the walk (k_probe), 0 = still measuring - the first batches of at least 2^18 tuples take the two in turn, timed
+ * with events on the context's stream, and the faster one stays (the results are the same either way).  MMANNOT_AMD_NO_FAST=1 /
+ * MMANNOT_AMD_FAST=1 in the environment (read at mm_ctx_create) decide without measuring. */
+int mm_probe_path(mm_ctx *ctx);
 
 /* Multi-GPU -y ratio.  regionCounts[set] += 1.0/nHits is a file-order double sum (mmannot.cpp:1730): ranks holding consecutive
  * blocks of the file chain it.  With mm_options.defer_ratio the batches are probed and sorted as usual but their accumulation is

@@ -75,6 +75,7 @@ SYMBOLS = {
     "mm_get_hit_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mm_get_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mm_get_probe_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mm_probe_path": (C.c_int, [C.c_void_p]),
     "mm_set_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mm_ratio_resolve": (C.c_int, [C.c_void_p]),
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),

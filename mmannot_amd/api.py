@@ -343,6 +343,10 @@ class Counter:
         check(lib().mm_get_probe_stats(self._h, a))
         return dict(walked=int(a[0]), grouped_batches=int(a[1]), passed_on=int(a[2]), fast_slot_bytes=int(a[3]))
 
+    def probe_path(self) -> str:
+        """which probe this counter runs where both apply: 'measuring', 'pipelined' (k_probe_fast) or 'walk' (k_probe)"""
+        return {0: "measuring", 1: "pipelined", 2: "walk"}.get(int(lib().mm_probe_path(self._h)), "?")
+
     def grouped_batches(self) -> int:
         """Batches whose multi-hit records were already grouped by read name (no name sort needed)."""
         a = (C.c_uint64 * 2)()

@@ -188,7 +188,8 @@ struct ProbeParams {
   const uint4 *slots;       // 64 B per bin: {nAct | nIv<<16, offset into flat, rec0} {rec1, rec2} ... 7 records
   const uint2 *flat;        // every bin's full record list (only read when a bin holds more than 7 records)
   const uint2 *chrSlot;     // per chromosome {first slot, number of slots}
-  const u32 *slotBits;      // one bit per slot: does it hold any record?  NULL when too few slots are empty for the test to pay
+  const u32 *slotBits;      // the slots' map, 2 bits per bin (FS_EMPTY / FS_GENERAL / FS_COVERED); NULL when it would save too few fetches
+  const u32 *slotCls;       // one byte per 8 bins (four to a word): element:6 | ok('+'):1 | ok('-'):1 of the interval covering a FS_COVERED bin
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
   const uint4 *fslots;      // fast slots: 32 B per bin (see mm_index_create); NULL = none
   const u32 *fbits;         // the map, 2 bits per fast slot: FS_EMPTY, FS_GENERAL (fetch the slot), FS_COVERED (the answer is in fcls)
@@ -508,7 +509,7 @@ __device__ __forceinline__ u32 slot_reach_count(const ProbeParams &P, u32 w1) {
 // -3 %, 30.1 % (512-base bins) +3 %.  Round 1's kernel, bound elsewhere, broke even at 42 %.)
 #define MM_SLOT_WALK(VISIT)                                                                      \
   for (u32 b_ = b0; b_ <= bl; ++b_) {                                                            \
-    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue; /* empty bin: no line to fetch */ \
+    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 4] >> (((cs.x + b_) & 15u) << 1)) & 3u)) continue; /* empty bin: no line to fetch */ \
     const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;                                        \
     const uint4 q0 = S_[0], q1 = S_[1];                                                          \
     const u32 nAct_ = q0.x & 0xffffu;                                                            \
@@ -567,7 +568,16 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
     if (rec_pass<OVL>(P, (RX), (RY), s, e, rstrand, o_, ie_)) hit |= 1ull << REC_TYPE(RY); \
   }
   for (u32 b_ = b0; b_ <= bl; ++b_) {
-    if (!EAGER && P.slotBits && !((P.slotBits[(cs.x + b_) >> 5] >> ((cs.x + b_) & 31u)) & 1u)) continue;
+    if (!EAGER && P.slotBits) {
+      const u32 sl_ = cs.x + b_, code_ = (P.slotBits[sl_ >> 4] >> ((sl_ & 15u) << 1)) & 3u;
+      if (code_ == FS_EMPTY) continue;                      // empty bin: no line to fetch
+      if (code_ == FS_COVERED && bl == b0) {                // one interval covers all this slot can be asked about: its element, if the strands allow
+        const u32 cb_ = (P.slotCls[sl_ >> 5] >> ((sl_ >> 3 & 3u) << 3)) & 0xFFu;
+        hit |= (u64) span_pass<OVL>(P, s, e, (cb_ >> rstrand) & 1u, s, e) << (cb_ >> 2);
+        ++walked_;
+        continue;
+      }
+    }
     const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;
     const uint4 q0 = S_[0], q1 = S_[1];
     uint4 q2 = make_uint4(0u, 0u, 0u, 0u), q3 = q2;
@@ -2403,7 +2413,7 @@ struct mm_index {
   u32 *d_actIdx = nullptr;
   uint4 *d_slots = nullptr;
   uint2 *d_flat = nullptr, *d_chrSlot = nullptr;
-  u32 *d_slotBits = nullptr;
+  u32 *d_slotBits = nullptr, *d_slotCls = nullptr;   // the slots' map (2 bits per bin) and the covering intervals' class bytes (one per 8 bins)
   size_t n_slotBits = 0;
   int *d_longEnd = nullptr;
   int sshift = 0;
@@ -2452,6 +2462,14 @@ struct mm_ctx {
   u32 *d_gkey = nullptr, *d_gpay = nullptr, *d_kA = nullptr, *d_vA = nullptr, *d_kB = nullptr, *d_vB = nullptr;
   u32 *d_hist = nullptr, *d_rowTot = nullptr, *d_M = nullptr, *d_seg = nullptr;
   int dcnt_cur = 0;
+  // which probe this context uses where both apply: 0 = still measuring, 1 = the pipelined one, 2 = the walk
+  int tune_choice = 0;
+  unsigned tune_turn = 0;
+  struct TuneSample { int path; size_t n; hipEvent_t a, b; };
+  std::vector<TuneSample> tune_pending;
+  double tune_ns_per_tuple[2] = {0, 0};
+  int tune_samples[2] = {0, 0};      // (the first sample of each path is not counted: code load, cold caches)
+  bool env_fast = false;
   u32 *d_dlist = nullptr, *d_dcnt = nullptr;   // tuples k_probe_fast passes on to k_probe_list: one region per wave of a tile, and the regions' lengths
   // A/B switches of the environment, read once (mm_ctx_create): MMANNOT_AMD_NO_FUSED_HIST, MMANNOT_AMD_GENERAL_PROBE, MMANNOT_AMD_FULL_INDEX_ONLY,
   // MMANNOT_AMD_NO_FAST (the round-2 walk instead of the pipelined one)
@@ -2486,6 +2504,7 @@ struct mm_ctx {
 
 static void free_runs(mm_ctx *c);
 static void free_run_pool(mm_ctx *c);
+static void tune_collect(mm_ctx *c);
 
 struct PhaseTimer {  // records an event pair around a group of launches when profiling is on
   mm_ctx *c; int phase; hipEvent_t a = nullptr, b = nullptr;
@@ -2500,6 +2519,22 @@ struct PhaseTimer {  // records an event pair around a group of launches when pr
   }
   ~PhaseTimer() { stop(); }
 };
+
+// timed batches that have finished -> per-path averages; decides once both paths have two counted samples
+static void tune_collect(mm_ctx *c) {
+  for (size_t k = 0; k < c->tune_pending.size();) {
+    mm_ctx::TuneSample &t = c->tune_pending[k];
+    if (hipEventQuery(t.b) != hipSuccess) { ++k; continue; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && c->tune_samples[t.path]++ > 0) c->tune_ns_per_tuple[t.path] += (double) ms * 1e6 / (double) t.n;
+    (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b);
+    c->tune_pending.erase(c->tune_pending.begin() + (long) k);
+  }
+  if (c->tune_choice == 0 && c->tune_samples[0] >= 2 && c->tune_samples[1] >= 2) {
+    const double f = c->tune_ns_per_tuple[0] / (c->tune_samples[0] - 1), w = c->tune_ns_per_tuple[1] / (c->tune_samples[1] - 1);
+    c->tune_choice = f <= w ? 1 : 2;
+  }
+}
 
 static int device_check(int device) {
   int n = 0;
@@ -2606,7 +2641,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
   // ---- compact slot index (see slot_walk)
   std::vector<uint2> chrSlot(n_chromosomes, make_uint2(0u, 0u));
   std::vector<uint4> slots;
-  std::vector<u32> slotBits;
+  std::vector<u32> slotBits, slotCls;
   std::vector<uint2> flat;
   std::vector<int> longEnd;
   std::vector<uint4> fslots;
@@ -2691,10 +2726,38 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     }
     if (longEnd.size() >= REC_LEN_MASK) { delete ix; return fail(MM_ERR_RANGE, "mm_index_create: too many very long intervals"); }
     slots.assign(ns * 4, make_uint4(0u, 0u, 0u, 0u));
-    slotBits.assign((ns + 31) / 32 + 1, 0u);
+    // the slots' map, 2 bits per bin: FS_EMPTY (no line to fetch), FS_GENERAL, or FS_COVERED - the bin holds nothing but one interval open at
+    // its left edge that reaches past its reach, so every read the one slot serves lies inside that interval and the answer is the
+    // interval's element if the strands allow: element and ok bits are in slotCls (one byte per 8 bins; bins of a group covered by
+    // different elements stay FS_GENERAL), and no slot is fetched (round 3; as for the fast slots below)
+    slotBits.assign((ns + 15) / 16 + 1, 0u);
+    slotCls.assign(((ns + 7) / 8 + 3) / 4 + 1, 0u);
+    u64 nCovered = 0;
+    {
+      unsigned char *cls = (unsigned char *) slotCls.data();
+      std::vector<unsigned char> have_cls((ns + 7) / 8, 0);
+      for (int c = 0; c < n_chromosomes; ++c) {
+        if (!seen[c]) continue;
+        for (u32 b = 0; b < sN[c]; ++b) {
+          const u64 k = (u64) sBase[c] + b;
+          const u32 total = nAct[k] + nIv[k] + nOvh[k];
+          if (!total) continue;
+          u32 code = FS_GENERAL;
+          if (total == 1 && nAct[k] == 1) {
+            const uint2 r = flat[off[k]];
+            const int64_t ie = (r.y & REC_LONG) ? (int64_t) longEnd[r.y & REC_LEN_MASK] : (int64_t) r.x + (int64_t) (r.y & REC_LEN_MASK);
+            const unsigned char cl = (unsigned char) ((REC_TYPE(r.y) << 2) | ((r.y >> REC_OKBIT) & 3u));
+            if (ie >= ((int64_t) b << sh) + (int64_t) W + (int64_t) reach - 1 && b + 1 < sN[c]) {
+              if (!have_cls[k >> 3]) { have_cls[k >> 3] = 1; cls[k >> 3] = cl; }
+              if (cls[k >> 3] == cl) { code = FS_COVERED; ++nCovered; }
+            }
+          }
+          slotBits[k >> 4] |= code << ((k & 15) * 2);
+        }
+      }
+    }
     for (u64 k = 0; k < ns; ++k) {
       const u32 total = nAct[k] + nIv[k] + nOvh[k];
-      if (total) slotBits[k >> 5] |= 1u << (k & 31);
       u32 *w = (u32 *) &slots[k * 4];
       w[0] = nAct[k] | (nIv[k] << 16);
       w[1] = total <= 7 ? nOvh[k] : (u32) off[k];
@@ -2704,7 +2767,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     }
     u64 nonEmpty = 0;
     for (u64 k = 0; k < ns; ++k) nonEmpty += (nAct[k] + nIv[k] + nOvh[k]) ? 1 : 0;
-    if ((double) (ns - nonEmpty) < 0.33 * (double) ns) slotBits.clear();
+    if ((double) (ns - nonEmpty + nCovered) < 0.33 * (double) ns) { slotBits.clear(); slotCls.clear(); }   // (the look at the map is a dependent L2 access: it has to save a third of the fetches)
     // (Measured and rejected, round 2: storing the non-empty bins only - slot found through a running count kept beside each bitmap
     // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
     // SLOWER (0.354 -> 0.394 ms per 2^24 tuples): the rank arithmetic sits on the dependent chain and costs the 64-VGPR budget a spill.)
@@ -2857,7 +2920,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       (e = up((void **) &ix->d_lineMask, ix->lineMask, 64 * sizeof(u64))) != hipSuccess ||
       (e = up((void **) &ix->d_slots, slots.data(), slots.size() * sizeof(uint4))) != hipSuccess ||
       (e = up((void **) &ix->d_flat, flat.data(), flat.size() * sizeof(uint2))) != hipSuccess ||
-      (!slotBits.empty() && (e = up((void **) &ix->d_slotBits, slotBits.data(), slotBits.size() * sizeof(u32))) != hipSuccess) ||
+      (!slotBits.empty() && ((e = up((void **) &ix->d_slotBits, slotBits.data(), slotBits.size() * sizeof(u32))) != hipSuccess ||
+                             (e = up((void **) &ix->d_slotCls, slotCls.data(), slotCls.size() * sizeof(u32))) != hipSuccess)) ||
       (e = up((void **) &ix->d_chrSlot, chrSlot.data(), (size_t) n_chromosomes * sizeof(uint2))) != hipSuccess ||
       (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess ||
       (!fslots.empty() && ((e = up((void **) &ix->d_fslots, fslots.data(), fslots.size() * sizeof(uint4))) != hipSuccess ||
@@ -2876,7 +2940,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
-  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fcls); (void) hipFree(ix->d_fext); (void) hipFree(ix->d_fchr);
+  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_slotCls); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fcls); (void) hipFree(ix->d_fext); (void) hipFree(ix->d_fchr);
   delete ix;
 }
 
@@ -2917,7 +2981,7 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   {
     auto on = [](const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; };
     c->env_no_fused_hist = on("MMANNOT_AMD_NO_FUSED_HIST"); c->env_general_probe = on("MMANNOT_AMD_GENERAL_PROBE");
-    c->env_full_index_only = on("MMANNOT_AMD_FULL_INDEX_ONLY"); c->env_no_fast = on("MMANNOT_AMD_NO_FAST");
+    c->env_full_index_only = on("MMANNOT_AMD_FULL_INDEX_ONLY"); c->env_no_fast = on("MMANNOT_AMD_NO_FAST"); c->env_fast = on("MMANNOT_AMD_FAST");
   }
   if (stream) c->stream = (hipStream_t) stream;
   else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
@@ -2937,6 +3001,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   (void) hipSetDevice(c->ix->device);
   (void) hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { (void) hipEventDestroy(s.a); (void) hipEventDestroy(s.b); }
+  for (auto &t : c->tune_pending) { (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b); }
   free_runs(c);
   free_run_pool(c);
   (void) hipFree(c->d_xkeys); (void) hipFree(c->d_xsums);
@@ -3033,7 +3098,7 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
   P.fslots = ix->d_fslots; P.fbits = ix->d_fbits; P.fcls = ix->d_fcls; P.fext = (const uint4 *) ix->d_fext; P.fextClass[0] = ix->fextClass[0]; P.fextClass[1] = ix->fextClass[1]; P.fextClass[2] = ix->fextClass[2]; P.fchr = ix->d_fchr; P.fLmax = ix->fLmax; P.fshift = (u32) ix->fshift; P.freach = ix->freach;
-  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
+  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.slotCls = ix->d_slotCls; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
   P.useSlots = c->env_full_index_only ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
@@ -3230,8 +3295,25 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   int var = PV_GENERAL;
   if (P.useSlots && P.nchr <= (u32) MM_LDS_CHR && !P.keep && P.strategy != MM_STRAT_RANDOM && !c->env_general_probe)
     var = ratio ? (fuse_hist ? PV_RATIO_HIST : PV_RATIO) : ((dflt && need_groups) ? (fuse_hist ? PV_GROUPS_HIST : PV_GROUPS) : PV_COUNT);
-  // the pipelined walk over the fast slots (k_probe_fast) + the list of what it passes on (k_probe_list), where the index has them
-  const bool fast = var != PV_GENERAL && P.fslots != nullptr && !c->env_no_fast;
+  // the pipelined walk over the fast slots (k_probe_fast) + the list of what it passes on (k_probe_list), where the index has them - or
+  // k_probe's walk: same results, and which of the two is faster depends on annotation and options (measured on one box, same
+  // batches: HS38-shaped, inclusion: 301 against 284 us per 2^24 tuples; Flybase6-shaped, -l 50: 183 against 229; profiles/r03c_*).
+  // So a context measures: its first batches of at least 2^18 tuples take the two in turn, each bracketed by events, and once both
+  // have a second timed batch (the first of each loads code) the faster one stays (mm_probe_path; MMANNOT_AMD_NO_FAST / MMANNOT_AMD_FAST in the environment decide without
+  // measuring).
+  bool fast = var != PV_GENERAL && P.fslots != nullptr && !c->env_no_fast;
+  int tune_path = -1;
+  if (fast && !c->env_fast && c->tune_choice == 0) {
+    tune_collect(c);
+    if (c->tune_choice == 0) {
+      tune_path = (c->tune_turn++ & 1) ? 1 : 0;                  // 0 = pipelined, 1 = walk
+      fast = tune_path == 0;
+    }
+  }
+  if (fast && c->tune_choice == 2) fast = false;
+  hipEvent_t tune_a = nullptr, tune_b = nullptr;
+  if (tune_path >= 0 && n >= ((size_t) 1 << 18) && hipEventCreate(&tune_a) == hipSuccess && hipEventCreate(&tune_b) == hipSuccess)
+    (void) hipEventRecord(tune_a, c->stream);
   if (fast) {
     u32 *const dlist2 = c->d_dlist + (size_t) nblk * RS_TILE;        // the compacted list (the first half: the waves' regions)
     // the list's length: two counters used in turn - k_probe_list zeroes the other one for the next batch (no memset launch per batch)
@@ -3282,6 +3364,13 @@ static int annotate_impl(mm_ctx *c, const void *aln, bool fmt12, uint64_t qid_ba
   }
 #undef MM_LAUNCH_PROBE_VAR
 #undef MM_LAUNCH_PROBE
+  if (tune_a && tune_b) {
+    // (while it measures - four batches - the context waits for each timed batch: the host would otherwise be many batches ahead of the
+    // device before the first event completes, and the whole input would be spent taking turns)
+    (void) hipEventRecord(tune_b, c->stream); c->tune_pending.push_back({tune_path, n, tune_a, tune_b});
+    (void) hipEventSynchronize(tune_b);
+    tune_collect(c);
+  }
   }
   bool huge_nh = false;                                  // an NH >= 65535 can only come through the side list
   for (size_t k = 0; k < n_big && !huge_nh; ++k) huge_nh = big[k].nh >= 0xFFFFu;
@@ -3622,6 +3711,15 @@ extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
   HIPCHK(hipMemcpyAsync(out, c->d_walk, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MM_OK;
+}
+
+extern "C" int mm_probe_path(mm_ctx *c) {
+  if (!c) return -1;
+  if (c->env_no_fast || !c->ix->d_fslots) return 2;
+  if (c->env_fast) return 1;
+  (void) hipSetDevice(c->ix->device);
+  tune_collect(c);
+  return c->tune_choice;
 }
 
 extern "C" int mm_get_probe_stats(mm_ctx *c, uint64_t out[4]) {

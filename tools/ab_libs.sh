@@ -4,11 +4,12 @@
 cd "$(dirname "$0")/.."
 for rep in 1 2; do
   for w in "$@"; do
-    for lib in $AB_LIBS; do
-      MMANNOT_AMD_LIB=$PWD/$lib timeout -k 10 200 python3 bench.py --workload $w --steps 12 --warmup 2 --no-cpu-baseline --legs resident 2>/dev/null | python3 -c "
+    for ent in $AB_LIBS; do            # "path/to/lib.so" or "path/to/lib.so:VAR=1" (an environment switch of that build)
+      lib=${ent%%:*}; var=${ent#*:}; [ "$var" = "$ent" ] && var=MM_AB_NONE=1
+      env $var MMANNOT_AMD_LIB=$PWD/$lib timeout -k 10 200 python3 bench.py --workload $w --steps 12 --warmup 2 --no-cpu-baseline --legs resident 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('rep $rep  $w  %-22s probe %.1f us   kernel_only %.2f G/s   passed on %.4f' % ('$lib', d['roofline']['avg_launch_ms'] * 1e3, d['kernel_only']['value'] / 1e9, d['roofline'].get('passed_on_frac', -1)))"
+print('rep $rep  $w  %-44s probe %.1f us   kernel_only %.2f G/s   passed on %.4f  path %s' % ('$ent', d['roofline']['avg_launch_ms'] * 1e3, d['kernel_only']['value'] / 1e9, d['roofline'].get('passed_on_frac', -1), d['roofline'].get('probe_path', '?')))"
     done
   done
 done
