@@ -7,11 +7,13 @@ One process per GPU (the driver launches N>1 through torch.distributed.run; back
 A step = one batch of 2^B synthetic 16-byte alignment tuples pushed through mm_annotate_batch: probe -> strand / -l filter ->
 priority selection -> multi-hit merge -> per-set counts.  Two legs run in the same invocation, on the same batches:
 
-  leg "from host" -> `value` (the metric of record, SURVEY.md 8d / BASELINE.md 4.3): the tuple batches start in PINNED HOST memory;
-      the timed region holds the hipMemcpyAsync of every batch (the library's copy stream, overlapped with the kernels of the
-      previous batch), all kernels, the end-of-file flush and the cross-rank table merge.  `h2d` reports the link rate.
-  leg "resident"  -> `kernel_only`: the same batches already resident in HBM (no copy in the timed region); this is the leg
-      the `roofline` block of the dominant kernel is measured on, with HIP events around its launches.
+  leg "resident"  -> `value` (and `kernel_only`, the same figure with the step's own roofline): the tuple batches are resident in HBM
+      when the timed region starts; the region holds all kernels, the end-of-file flush and the cross-rank table merge.  This is the
+      leg the `roofline` block of the dominant kernel is measured on, with HIP events around its launches.  (Rounds 1 and 2 quoted the
+      host-fed rate as `value`, after SURVEY.md 8d; the task statement wants the HBM-resident one, the PCIe-inclusive one beside it.)
+  leg "from host" -> `from_host`: the same batches start in PINNED HOST memory; the timed region also holds the hipMemcpyAsync of
+      every batch (the library's copy stream, overlapped with the kernels of the previous batch).  `h2d` reports the link rate -
+      this leg runs at the PCIe link's pace (90 % of Gen5 x16), an order of magnitude below the kernels'.
 
 Prints ONE JSON line on rank 0.
 
@@ -83,6 +85,8 @@ def main():
     ap.add_argument("--annotation-scale", type=float, default=0.0, help="scale sensitivity: multiply the workload's gene counts by this instead of its own "
                     "factor (c3: 1.5 -> 1.27 M intervals; 3.5 -> ~3 M, BASELINE.json's '~3M features')")
     ap.add_argument("--scaffolds", type=int, default=0, help="scale sensitivity: that many 60-kb scaffolds behind the chromosomes (> 256 reference names)")
+    ap.add_argument("--probe-events", type=int, default=1, help="measurement aid: 0 = no HIP events around the probe launches of the timed legs "
+                    "(the line of record needs them: roofline.avg_launch_ms)")
     ap.add_argument("--legs", default="both", choices=("both", "host", "resident"), help="profiling aid: run only one leg (the JSON line of record needs both)")
     ap.add_argument("--tuple-bytes", type=int, default=16, choices=(16, 12),
                     help="bytes per tuple on the link in the from-host leg that gives `value`: 16 = mm_aln (SURVEY.md 8d, the metric of record); "
@@ -163,9 +167,13 @@ def main():
     W_sc = 1 << scatter
     job_seed = args.seed * 1000003
 
+    # (the device generator knows 64 reference sequences: with --scaffolds the reads land on the chromosomes and the first scaffolds - the
+    # index, the chromosome table in global memory and the general probe instance that > 256 names select are what that run is about)
+    gen_len = np.ascontiguousarray(chr_len[:64])
+
     def gen(seed, first, n):
         a = torch.empty((n, 4), dtype=torch.int32, device=dev)
-        p = _lib.SynthParams(seed, first, read_len, nh_max, len(chr_len), chr_len.ctypes.data, scatter, pair)
+        p = _lib.SynthParams(seed, first, read_len, nh_max, len(gen_len), gen_len.ctypes.data, scatter, pair)
         _lib.check(_lib.lib().mm_synth_fill(a.data_ptr(), n, C.byref(p), stream))
         return a
 
@@ -274,7 +282,7 @@ def main():
             step(s)
         ctr.sync()
         # HIP events around the probe launches and the copies only: every recorded event costs a few microseconds of stream time
-        ctr.set_profiling(2)
+        ctr.set_profiling(2 if args.probe_events else 0)
         if multi:
             # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
             if strategy == "ratio":
@@ -349,14 +357,14 @@ def main():
     # (untimed, resident, batch by batch from the generator) and compares tables, counters and - under -y ratio - the sums' bit patterns.
     merge_check = None
     if multi and rank == 0:
-        lead_ = res_host if res_host is not None else res_dev
+        lead_ = res_dev if res_dev is not None else res_host
         merge_check = check_against_one_gpu(mm, torch, index, wl, gen, dict(strong=strong, by_name=by_name, world=world, nb=nb, B=B, Bg=Bg,
                                                                                job_seed=job_seed, single=single, nh_max=nh_max),
                                             (stream_qb, stream_qlo, stream_qbound), lead_[2], lead_[3], lead_[4])
         assert merge_check["verified"], merge_check
 
     if rank == 0:
-        lead = res_host if res_host is not None else res_dev
+        lead = res_dev if res_dev is not None else res_host          # `value`: the resident leg (--legs host: only that one ran)
         elapsed, _, masks, sums, stats = lead
         job = job_tuples_timed
         B = int(round(sum(sizes[args.warmup:]) / max(1, args.steps)))       # this rank's mean timed batch (strong scaling by name: sizes vary)
@@ -369,10 +377,11 @@ def main():
             "metric": "annotated alignments/sec", "value": job / elapsed, "unit": "alignments/s", "n_gpus": n_joined, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32/u64 (f64 only under -y ratio)", "data": "synthetic",
-            "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "order_elements": len(an.config),
+            "config": {"workload": wname, "batch_alignments_per_gpu": B, "intervals": int(len(an.start)), "chromosomes": int(len(chr_len)), "order_elements": len(an.config),
                        "index_bytes": info, "sharding": sharding,
-                       "input": f"{args.tuple_bytes}-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region" if res_host is not None
-                                else "tuples resident in HBM (--legs resident: NOT the metric of record)"},
+                       "input": "16-byte tuples resident in HBM when the timed region starts" + ("" if res_host is not None else " (--legs resident: no host-fed leg in this run)")
+                                if res_dev is not None else
+                                f"{args.tuple_bytes}-byte tuples in pinned host memory, hipMemcpyAsync inside the timed region (--legs host: NOT the metric of record)"},
             "stats": stats, "table_rows": int(len(masks)),
             # sha256 over the table sorted by element set (sets, sums' bit patterns) and the seven counters: equal digests = equal results.
             # --scaling strong: the same for every N (one stream); weak: N streams, comparable only at equal N
@@ -391,10 +400,14 @@ def main():
             link = link_b * B / avg_copy_s / 1e9 if avg_copy_s > 0 else 0.0
             out["h2d"] = {"bound": "pcie", "achieved": link, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": link / PCIE_PEAK_GBS,
                           "alg_bytes_per_alignment": B_ALG_H2D, "link_bytes_per_alignment": link_b, "avg_copy_ms": avg_copy_s * 1e3,
-                          "end_to_end": out["value"] / world * link_b / 1e9,
+                          "end_to_end": job / res_host[0] / world * link_b / 1e9,
                           "note": "achieved = bytes per tuple on the link x batch / average hipMemcpyAsync duration (HIP events on the copy stream, "
-                                  "timed region); end_to_end = per-GPU value x those bytes: what the whole pipeline sustains on the link"}
-            if args.tuple_bytes != 16:
+                                  "timed region); end_to_end = per-GPU host-fed rate x those bytes: what the whole pipeline sustains on the link"}
+            out["from_host"] = {"value": job / res_host[0], "unit": "alignments/s", "ms_per_step": res_host[0] / args.steps * 1e3,
+                                "link_bytes_per_alignment": link_b,
+                                "note": "same job, same table: the batches start in pinned host memory, every hipMemcpyAsync is inside the timed region "
+                                        "(overlapped with the previous batch's kernels) - the PCIe-inclusive rate, bound by the link (h2d)"}
+            if res_dev is None and args.tuple_bytes != 16:
                 out["metric"] = "annotated alignments/sec, tuples packed to 12 B on the link (informational; the metric of record uses 16-B tuples)"
         if res_pk is not None:
             p_el = res_pk[0]
@@ -410,13 +423,13 @@ def main():
             probe_ms, probe_n = k_ph["probe"]
             avg_probe_s = probe_ms / max(1, probe_n) / 1e3
             achieved = B_ALG_PROBE * B / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
-            traffic, traffic_source = pmc_traffic(args.workload)
+            traffic, traffic_source = pmc_traffic(args.workload, probe_path)
             # whole step against the HBM roof with SURVEY.md 8d's algorithmic bytes: 32 B per alignment (stream in + index probe), 49 B with
             # the multi-hit merge (-y default, NH > 1: + 16 B mask RMW + 8 B per group)
             b_step = 49.0 if (strategy == "default" and nh_max > 1) else 32.0
             step_gbs = job / k_el / world * b_step / 1e9
             out["kernel_only"] = {"value": job / k_el, "unit": "alignments/s", "ms_per_step": k_el / args.steps * 1e3,
-                                  "note": "same batches resident in HBM when the timed region starts (no copy); the roofline leg",
+                                  "note": "= value: the batches resident in HBM when the timed region starts (no copy); the roofline leg",
                                   "step_roofline": {"bound": "hbm", "alg_bytes_per_alignment": b_step, "achieved": step_gbs, "peak": 8000.0,
                                                     "unit": "GB/s", "frac": step_gbs / 8000.0}}
             out["roofline"] = {"bound": "hbm", "kernel": {"pipelined": "k_probe_fast + k_probe_list", "walk": "k_probe"}.get(probe_path, "k_probe / k_probe_fast (undecided)"),
@@ -431,8 +444,8 @@ def main():
         out["phase_ms_per_step"] = {p: phases_all[p][0] / max(1, n_phase) for p in phases_all}
         out["phase_pass"] = f"separate untimed pass of {n_phase} resident steps with events around every phase"
         if want_cpu:
-            port = cpu_baseline(args, an, wl, chr_len)
-            ref = cpu_baseline_reference(args, an, wl, chr_len, index, cfg)
+            port = cpu_baseline(args, an, wl, gen_len)
+            ref = cpu_baseline_reference(args, an, wl, gen_len, index, cfg)
             if ref is not None:
                 ref["port_single_thread"] = {k: port[k] for k in ("value", "sample")}
                 out["cpu_baseline"] = ref
@@ -476,8 +489,8 @@ def mm_device_sha() -> str:
         return "unknown"
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_probe launch from the tracked counter summary (profiles/pmc_latest.json, written by tools/prof_summary.py from
+def pmc_traffic(workload, probe_path="walk"):
+    """HBM bytes per probe launch (k_probe, or k_probe_fast + k_probe_list where the context chose the pipelined probe) from the tracked counter summary (profiles/pmc_latest.json, written by tools/prof_summary.py from
     separate rocprofv3 --pmc passes of `bench.py --legs resident`).  The figure comes from a FILE, not from this run: it is handed out
     only while the kernel source it was collected on is the one this run was built from (sha256 of mm_device.hip), and labelled."""
     pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -485,7 +498,7 @@ def pmc_traffic(workload):
         e = json.load(open(pj)).get(workload, {})
     except Exception:
         return None, "no counter summary (profiles/pmc_latest.json)"
-    t = e.get("k_probe_hbm_bytes_per_launch")
+    t = e.get("k_probe_fast_plus_list_hbm_bytes_per_launch" if probe_path == "pipelined" else "k_probe_hbm_bytes_per_launch")
     if t is None:
         return None, "no counter summary for this workload"
     have, now = e.get("mm_device_sha"), mm_device_sha()

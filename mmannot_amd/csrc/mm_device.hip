@@ -188,14 +188,18 @@ struct ProbeParams {
   const uint4 *slots;       // 64 B per bin: {nAct | nIv<<16, offset into flat, rec0} {rec1, rec2} ... 7 records
   const uint2 *flat;        // every bin's full record list (only read when a bin holds more than 7 records)
   const uint2 *chrSlot;     // per chromosome {first slot, number of slots}
-  const u32 *slotBits;      // the slots' map, 2 bits per bin (FS_EMPTY / FS_GENERAL / FS_COVERED); NULL when it would save too few fetches
-  const u32 *slotCls;       // one byte per 8 bins (four to a word): element:6 | ok('+'):1 | ok('-'):1 of the interval covering a FS_COVERED bin
+  const u32 *slotBits;      // the slots' map, one word per 8 bins: bits 0-15 = 2 bits per bin (FS_EMPTY / FS_GENERAL / FS_COVERED), bits 16-23 =
+                            // element:6 | ok('+'):1 | ok('-'):1 of the interval covering the group's FS_COVERED bins (code and class in ONE
+                            // L2 access); NULL when the map would save too few fetches
   const int *longEnd;       // true end of the few intervals too long for the 22-bit length field
   const uint4 *fslots;      // fast slots: 32 B per bin (see mm_index_create); NULL = none
   const u32 *fbits;         // the map, 2 bits per fast slot: FS_EMPTY, FS_GENERAL (fetch the slot), FS_COVERED (the answer is in fcls)
+  const u32 *fcls;          // one byte per 8 fast slots (four to a word): element:6 | ok('+'):1 | ok('-'):1 of the covering interval.
+                            // (Separate from the map here, unlike slotBits: k_probe_fast WAITS for the map word and only requests the class
+                            // word, so the denser map is what counts - merged, HS38-shaped batches took 335 instead of 301 us;
+                            // profiles/r03g_ab_merged_map.txt)
   u32 fextClass[3];         // extension blocks numbered below these hold at most 11 / 15 / 23 records (3 / 4 / 6 quads to request)
   const uint4 *fext;        // extension blocks: 128 B = count + up to 31 records, for the bins whose slot says FS_OVERFLOW | block
-  const u32 *fcls;          // one byte per 8 fast slots (four to a word): element:6 | ok('+'):1 | ok('-'):1 of the covering interval
   const uint2 *fchr;        // per chromosome {first fast slot, number of fast slots}
   u32 fLmax;                // longest read the fast slots answer exactly
   u32 fshift, freach;       // the fast slots' own bin width and reach
@@ -509,7 +513,7 @@ __device__ __forceinline__ u32 slot_reach_count(const ProbeParams &P, u32 w1) {
 // -3 %, 30.1 % (512-base bins) +3 %.  Round 1's kernel, bound elsewhere, broke even at 42 %.)
 #define MM_SLOT_WALK(VISIT)                                                                      \
   for (u32 b_ = b0; b_ <= bl; ++b_) {                                                            \
-    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 4] >> (((cs.x + b_) & 15u) << 1)) & 3u)) continue; /* empty bin: no line to fetch */ \
+    if (P.slotBits && !((P.slotBits[(cs.x + b_) >> 3] >> (((cs.x + b_) & 7u) << 1)) & 3u)) continue; /* empty bin: no line to fetch */ \
     const uint4 *S_ = P.slots + (size_t) (cs.x + b_) * 4;                                        \
     const uint4 q0 = S_[0], q1 = S_[1];                                                          \
     const u32 nAct_ = q0.x & 0xffffu;                                                            \
@@ -569,10 +573,10 @@ __device__ __forceinline__ u64 probe_slots(const ProbeParams &P, const uint2 *ch
   }
   for (u32 b_ = b0; b_ <= bl; ++b_) {
     if (!EAGER && P.slotBits) {
-      const u32 sl_ = cs.x + b_, code_ = (P.slotBits[sl_ >> 4] >> ((sl_ & 15u) << 1)) & 3u;
+      const u32 sl_ = cs.x + b_, mw_ = P.slotBits[sl_ >> 3], code_ = (mw_ >> ((sl_ & 7u) << 1)) & 3u;
       if (code_ == FS_EMPTY) continue;                      // empty bin: no line to fetch
       if (code_ == FS_COVERED && bl == b0) {                // one interval covers all this slot can be asked about: its element, if the strands allow
-        const u32 cb_ = (P.slotCls[sl_ >> 5] >> ((sl_ >> 3 & 3u) << 3)) & 0xFFu;
+        const u32 cb_ = (mw_ >> 16) & 0xFFu;
         hit |= (u64) span_pass<OVL>(P, s, e, (cb_ >> rstrand) & 1u, s, e) << (cb_ >> 2);
         ++walked_;
         continue;
@@ -2413,7 +2417,7 @@ struct mm_index {
   u32 *d_actIdx = nullptr;
   uint4 *d_slots = nullptr;
   uint2 *d_flat = nullptr, *d_chrSlot = nullptr;
-  u32 *d_slotBits = nullptr, *d_slotCls = nullptr;   // the slots' map (2 bits per bin) and the covering intervals' class bytes (one per 8 bins)
+  u32 *d_slotBits = nullptr;   // the slots' map: per 8 bins one word of 2-bit codes + the covering intervals' class byte
   size_t n_slotBits = 0;
   int *d_longEnd = nullptr;
   int sshift = 0;
@@ -2423,9 +2427,9 @@ struct mm_index {
   // bin width does not allow the encoding (see FS_* below)
   uint4 *d_fslots = nullptr;
   u32 *d_fbits = nullptr;  // the map: 2 bits per fast slot
+  u32 *d_fcls = nullptr;   // one byte per 8 fast slots: element and ok bits of the interval covering them (FS_COVERED)
   u32 *d_fext = nullptr;   // extension blocks (32 words each) of the bins with 8 to 31 records
   u32 fextClass[4] = {0, 0, 0, 0};   // blocks numbered below fextClass[c] hold at most 11 / 15 / 23 / 31 records
-  u32 *d_fcls = nullptr;   // one byte per 8 fast slots: element and ok bits of the interval covering them (FS_COVERED)
   uint2 *d_fchr = nullptr; // per chromosome {first fast slot, number of fast slots}
   int fshift = 0;          // log2 of the fast slots' bin width (may be one less than sshift)
   u32 freach = 0;
@@ -2544,6 +2548,16 @@ static int device_check(int device) {
   if (device < 0 || device >= n) return fail(MM_ERR_ARG, "device index out of range");
   HIPCHK(hipSetDevice(device));
   return MM_OK;
+}
+
+// The maps as the kernels read them: per group of 8 bins one word - the bins' 2-bit codes in bits 0-15, the group's class byte in
+// bits 16-23 (the builders above fill the two as separate arrays: 16 codes to a word, four class bytes to a word).
+static std::vector<u32> merge_map(const std::vector<u32> &bits, const std::vector<u32> &cls, u64 ns) {
+  const unsigned char *cb = (const unsigned char *) cls.data();
+  const u64 ng = (ns + 7) / 8;
+  std::vector<u32> m(ng + 2, 0u);                       // (+ the slack the old layout had: a lane without a slot reads word 0, nothing reads behind ng)
+  for (u64 g = 0; g < ng; ++g) m[g] = ((bits[g >> 1] >> ((g & 1) * 16)) & 0xFFFFu) | ((u32) cb[g] << 16);
+  return m;
 }
 
 extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_chromosomes, size_t n_iv, const int32_t *chr,
@@ -2771,6 +2785,8 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     // (Measured and rejected, round 2: storing the non-empty bins only - slot found through a running count kept beside each bitmap
     // word, one 8-byte L2 access for "empty?" and "where?".  The HS38-scale table shrinks from 193 to 96 MB, yet the probe got 11 %
     // SLOWER (0.354 -> 0.394 ms per 2^24 tuples): the rank arithmetic sits on the dependent chain and costs the 64-VGPR budget a spill.)
+    // code bits and class byte of a group of 8 bins in one word: what the kernels read (one L2 access, not two)
+    if (!slotBits.empty()) slotBits = merge_map(slotBits, slotCls, ns);
     ix->n_slots = ns; ix->n_flat = off[ns]; ix->n_slotBits = slotBits.size();
   }
   // ---- fast slots (k_probe_fast): per bin 32 bytes = header + up to 7 records of 4 bytes, relative to the bin's first base.
@@ -2920,8 +2936,7 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
       (e = up((void **) &ix->d_lineMask, ix->lineMask, 64 * sizeof(u64))) != hipSuccess ||
       (e = up((void **) &ix->d_slots, slots.data(), slots.size() * sizeof(uint4))) != hipSuccess ||
       (e = up((void **) &ix->d_flat, flat.data(), flat.size() * sizeof(uint2))) != hipSuccess ||
-      (!slotBits.empty() && ((e = up((void **) &ix->d_slotBits, slotBits.data(), slotBits.size() * sizeof(u32))) != hipSuccess ||
-                             (e = up((void **) &ix->d_slotCls, slotCls.data(), slotCls.size() * sizeof(u32))) != hipSuccess)) ||
+      (!slotBits.empty() && (e = up((void **) &ix->d_slotBits, slotBits.data(), slotBits.size() * sizeof(u32))) != hipSuccess) ||
       (e = up((void **) &ix->d_chrSlot, chrSlot.data(), (size_t) n_chromosomes * sizeof(uint2))) != hipSuccess ||
       (e = up((void **) &ix->d_longEnd, longEnd.data(), longEnd.size() * sizeof(int))) != hipSuccess ||
       (!fslots.empty() && ((e = up((void **) &ix->d_fslots, fslots.data(), fslots.size() * sizeof(uint4))) != hipSuccess ||
@@ -2940,7 +2955,7 @@ extern "C" void mm_index_destroy(mm_index *ix) {
   if (!ix) return;
   (void) hipFree(ix->d_iv); (void) hipFree(ix->d_act); (void) hipFree(ix->d_actIdx); (void) hipFree(ix->d_bins);
   (void) hipFree(ix->d_chrInfo); (void) hipFree(ix->d_lineMask); (void) hipFree(ix->d_slots); (void) hipFree(ix->d_flat); (void) hipFree(ix->d_chrSlot); (void) hipFree(ix->d_longEnd);
-  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_slotCls); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fcls); (void) hipFree(ix->d_fext); (void) hipFree(ix->d_fchr);
+  (void) hipFree(ix->d_slotBits); (void) hipFree(ix->d_fslots); (void) hipFree(ix->d_fbits); (void) hipFree(ix->d_fcls); (void) hipFree(ix->d_fext); (void) hipFree(ix->d_fchr);
   delete ix;
 }
 
@@ -3098,7 +3113,7 @@ static void fill_params(const mm_ctx *c, ProbeParams &P) {
   P.iv = ix->d_iv; P.act = ix->d_act; P.bins = ix->d_bins;
   P.chrInfo = ix->d_chrInfo;
   P.fslots = ix->d_fslots; P.fbits = ix->d_fbits; P.fcls = ix->d_fcls; P.fext = (const uint4 *) ix->d_fext; P.fextClass[0] = ix->fextClass[0]; P.fextClass[1] = ix->fextClass[1]; P.fextClass[2] = ix->fextClass[2]; P.fchr = ix->d_fchr; P.fLmax = ix->fLmax; P.fshift = (u32) ix->fshift; P.freach = ix->freach;
-  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.slotCls = ix->d_slotCls; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
+  P.slots = ix->d_slots; P.flat = ix->d_flat; P.chrSlot = ix->d_chrSlot; P.slotBits = ix->d_slotBits; P.longEnd = ix->d_longEnd; P.sshift = (u32) ix->sshift; P.reach = ix->reach;
   P.useSlots = c->env_full_index_only ? 0 : 1;
   P.nchr = (u32) ix->nchr; P.shift = (u32) ix->shift;
   P.elemF = ix->elemF; P.elemR = ix->elemR; P.elemUp = ix->elemUp; P.elemDown = ix->elemDown;
@@ -3716,6 +3731,8 @@ extern "C" int mm_get_walk_stats(mm_ctx *c, uint64_t out[2]) {
 extern "C" int mm_probe_path(mm_ctx *c) {
   if (!c) return -1;
   if (c->env_no_fast || !c->ix->d_fslots) return 2;
+  // launches the pipelined probe never takes (annotate_impl: the general instance of k_probe serves them)
+  if (c->ix->nchr > MM_LDS_CHR || c->opt.keep_hit_masks || c->opt.strategy == MM_STRAT_RANDOM || c->env_general_probe || c->env_full_index_only) return 2;
   if (c->env_fast) return 1;
   (void) hipSetDevice(c->ix->device);
   tune_collect(c);

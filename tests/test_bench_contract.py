@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-        "config", "roofline", "kernel_only", "h2d"}
+        "config", "roofline", "kernel_only", "h2d", "from_host"}
 
 
 def _json_lines(out):
@@ -31,10 +31,12 @@ def test_single_rank_contract(gpu_lib):
     assert isinstance(r["traffic_source"], str) and (r["traffic"] is None or "file" in r["traffic_source"])   # a counter figure by file says so
     assert len(d["table_digest"]) == 32 and "merge_check" not in d
     assert d["value"] > 0 and d["stats"]["nHits"] == 4 * (1 << 20)
-    # `value` is the rate from pinned host tuples (copies inside the timed region); the HBM-resident rate is reported beside it
-    h, k = d["h2d"], d["kernel_only"]
+    # `value` is the rate with the tuples resident in HBM when the timed region starts; the rate from pinned host tuples (copies inside
+    # the timed region) is reported beside it
+    h, k, fh = d["h2d"], d["kernel_only"], d["from_host"]
     assert h["bound"] == "pcie" and h["unit"] == "GB/s" and h["alg_bytes_per_alignment"] == 16.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
-    assert k["value"] > 0 and "pinned host" in d["config"]["input"] and "16-byte" in d["config"]["input"]
+    assert k["value"] == d["value"] and "resident in HBM" in d["config"]["input"] and "16-byte" in d["config"]["input"]
+    assert 0 < fh["value"] <= d["value"] * 1.05 and abs(h["end_to_end"] - fh["value"] * 16.0 / 1e9) < 1e-6
     assert 0 < k["step_roofline"]["frac"] < 1
     p = d["from_host_packed12"]      # the same job with 12 bytes per tuple on the link, reported beside the metric of record
     assert p["value"] > 0 and p["link_bytes_per_alignment"] == 12.0

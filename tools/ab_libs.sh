@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 for rep in 1 2; do
   for w in "$@"; do
     for ent in $AB_LIBS; do            # "path/to/lib.so" or "path/to/lib.so:VAR=1" (an environment switch of that build)
-      lib=${ent%%:*}; var=${ent#*:}; [ "$var" = "$ent" ] && var=MM_AB_NONE=1
+      lib=${ent%%:*}; var=${ent#*:}; [ "$var" = "$ent" ] && var=MM_AB_NONE=1; var=${var//,/ }   # several switches: A=1,B=1
       env $var MMANNOT_AMD_LIB=$PWD/$lib timeout -k 10 200 python3 bench.py --workload $w --steps 12 --warmup 2 --no-cpu-baseline --legs resident 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
