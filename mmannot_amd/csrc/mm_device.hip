@@ -2742,8 +2742,9 @@ extern "C" int mm_index_create(mm_index **out, const mm_elements *el, int32_t n_
     slots.assign(ns * 4, make_uint4(0u, 0u, 0u, 0u));
     // the slots' map, 2 bits per bin: FS_EMPTY (no line to fetch), FS_GENERAL, or FS_COVERED - the bin holds nothing but one interval open at
     // its left edge that reaches past its reach, so every read the one slot serves lies inside that interval and the answer is the
-    // interval's element if the strands allow: element and ok bits are in slotCls (one byte per 8 bins; bins of a group covered by
-    // different elements stay FS_GENERAL), and no slot is fetched (round 3; as for the fast slots below)
+    // interval's element if the strands allow: element and ok bits are the group's class byte (one per 8 bins; bins of a group covered by
+    // different elements stay FS_GENERAL), and no slot is fetched (round 3; as for the fast slots below).  Built as two arrays here,
+    // merged into one word per 8 bins for the device (merge_map)
     slotBits.assign((ns + 15) / 16 + 1, 0u);
     slotCls.assign(((ns + 7) / 8 + 3) / 4 + 1, 0u);
     u64 nCovered = 0;

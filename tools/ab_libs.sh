@@ -9,7 +9,8 @@ for rep in 1 2; do
       env $var MMANNOT_AMD_LIB=$PWD/$lib timeout -k 10 200 python3 bench.py --workload $w --steps 12 --warmup 2 --no-cpu-baseline --legs resident 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('rep $rep  $w  %-44s probe %.1f us   kernel_only %.2f G/s   passed on %.4f  path %s' % ('$ent', d['roofline']['avg_launch_ms'] * 1e3, d['kernel_only']['value'] / 1e9, d['roofline'].get('passed_on_frac', -1), d['roofline'].get('probe_path', '?')))"
+ph = d['phase_ms_per_step']
+print('rep $rep  $w  %-44s probe %.1f us   kernel_only %.2f G/s   passed on %.4f  path %s  sort %.1f merge %.1f us' % ('$ent', d['roofline']['avg_launch_ms'] * 1e3, d['kernel_only']['value'] / 1e9, d['roofline'].get('passed_on_frac', -1), d['roofline'].get('probe_path', '?'), ph['sort'] * 1e3, ph['merge'] * 1e3))"
     done
   done
 done
