@@ -108,7 +108,7 @@ def main():
     import torch.distributed as dist
     import mmannot_amd as mm
     from mmannot_amd import _lib, synth
-    from mmannot_amd.dist import chain_ratio, merge_counts, warm_up
+    from mmannot_amd.dist import chain_ratio, merge_counts_device, warm_up
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -284,24 +284,25 @@ def main():
         # HIP events around the probe launches and the copies only: every recorded event costs a few microseconds of stream time
         ctr.set_profiling(2 if args.probe_events else 0)
         if multi:
-            # first use of a collective (and of torch.unique / searchsorted) sets up RCCL channels and loads kernels: not part of a step
+            # first use of a collective (and of torch.unique / scatter_add) sets up RCCL channels and loads kernels: not part of a step
             if strategy == "ratio":
                 warm_up(device=comm_dev, p2p=True)
             else:
-                merge_counts(*ctr.getCounts(), ctr.stats(), device=comm_dev)
+                merge_counts_device(ctr, dev, rehearsal=True)      # (empty tables: the counter keeps its warm-up batches as they are)
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(args.warmup, nb):
             step(s)
         ctr.flush()                                   # end of file: pending groups (mmannot.cpp:1783-1792)
-        stats = ctr.stats()
         if strategy == "ratio" and multi:         # ranks hold consecutive blocks of the stream: chain the ordered double sums
             # (row chunks pipeline the chain; they pay when the hops stay on the devices - RCCL - and cost more than they hide through the host)
-            masks, sums, stats = chain_ratio(ctr, stats, device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "8" if comm_dev.type == "cuda" else "1")))
+            masks, sums, stats = chain_ratio(ctr, ctr.stats(), device=comm_dev, n_chunks=int(os.environ.get("MM_RATIO_CHUNKS", "8" if comm_dev.type == "cuda" else "1")))
+        elif multi:                               # tables add up: one all_gather of the fixed-size tables, summed on every GPU (dist.merge_counts_device)
+            masks, sums, stats = merge_counts_device(ctr, dev)
         else:
+            stats = ctr.stats()
             masks, sums = ctr.getCounts()
-            masks, sums, stats = merge_counts(masks, sums, stats, device=comm_dev)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -509,7 +510,7 @@ def pmc_traffic(workload, probe_path="walk"):
 
 def check_against_one_gpu(mm, torch, index, wl, gen, J, qfun, masks, sums, stats):
     """(rank 0, after the timed legs) every rank's share of the job once more on THIS GPU, one context, no collective - the merged
-    table, counters and (ratio) sum bit patterns must be the same.  What it checks is the exchange step: dist.merge_counts /
+    table, counters and (ratio) sum bit patterns must be the same.  What it checks is the exchange step: dist.merge_counts_device /
     dist.chain_ratio over RCCL against plain addition / plain file order."""
     stream_qb, stream_qlo, stream_qbound = qfun
     strategy = wl["strategy"]

@@ -230,6 +230,14 @@ int mm_ratio_replay(mm_ctx *ctx, size_t first, size_t count, uint32_t chunk, uin
 int mm_ratio_release(mm_ctx *ctx);
 int mm_ratio_reserve(mm_ctx *ctx, size_t n_runs, size_t batch_capacity);
 int mm_ratio_handoff(mm_ctx *src, mm_ctx *dst, uint32_t chunk, uint32_t n_chunks);
+/* -y default / unique, ranks of a multi-process job: tables add up (Counter::getCounts of every rank, mmannot.cpp:1803, summed).  For a
+ * merge that stays on the devices: d_keys[MM_TABLE_SLOTS] (0 = empty slot), d_counts[MM_TABLE_SLOTS], d_stats[MM_N_STATS], device to
+ * device on the context's stream (mm_sync before another stream reads them).  MM_ERR_STATE under -y ratio (sums do not add up). */
+int mm_table_export_counts_device(mm_ctx *ctx, uint64_t *d_keys, uint64_t *d_counts, uint64_t *d_stats);
+/* ... and back: n_tables (1..32) exported tables, each d_keys | d_counts | d_stats contiguous and `stride` 64-bit words apart (what an
+ * all_gather of every rank's export leaves in device memory), are added to this context's table and counters - all but table `own`,
+ * this context's.  Asynchronous on the context's stream.  mm_get_stats / mm_get_rows then return the whole job's result. */
+int mm_table_merge_counts_device(mm_ctx *ctx, const uint64_t *d_tables, size_t n_tables, size_t stride, size_t own);
 
 /* ---- one input on several GPUs (replaces the reference's thread-per-file pool, mmannot.cpp:2117-2143, which can only
  * spread whole files).  One context per device, each on its own copy of the index.

@@ -81,6 +81,8 @@ SYMBOLS = {
     "mm_ratio_resolve_n": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mm_ratio_pending": (C.c_size_t, [C.c_void_p]),
     "mm_table_export_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm_table_export_counts_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mm_table_merge_counts_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "mm_table_import_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
     "mm_ratio_replay": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32]),
     "mm_ratio_release": (C.c_int, [C.c_void_p]),

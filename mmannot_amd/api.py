@@ -284,11 +284,10 @@ class Counter:
     def getCounts(self):
         """Counter::getCounts mmannot.cpp:1803: (masks, sums) unsorted."""
         n = C.c_size_t(0)
-        check(lib().mm_get_rows(self._h, None, None, 0, C.byref(n)))
-        masks = np.zeros(max(1, n.value), dtype=np.uint64)
-        sums = np.zeros(max(1, n.value), dtype=np.float64)
+        masks = np.zeros(self.TABLE_SLOTS, dtype=np.uint64)      # (one call: the table cannot hold more rows than it has slots)
+        sums = np.zeros(self.TABLE_SLOTS, dtype=np.float64)
         check(lib().mm_get_rows(self._h, masks.ctypes.data, sums.ctypes.data, len(masks), C.byref(n)))
-        return masks[:n.value], sums[:n.value]
+        return masks[:n.value].copy(), sums[:n.value].copy()
 
     def set_row_sums(self, masks: np.ndarray, sums: np.ndarray):
         """-y ratio chaining: start this counter's rows from the sums of the rank holding the preceding block of the file."""
@@ -308,6 +307,14 @@ class Counter:
 
     def export_table_device(self, keys_ptr: int, sums_ptr: int):
         check(lib().mm_table_export_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(sums_ptr)))
+
+    def export_counts_device(self, keys_ptr: int, counts_ptr: int, stats_ptr: int):
+        """-y default / unique: sets, integer counts and the seven counters, device to device on the context's stream (for dist.merge_counts_device)."""
+        check(lib().mm_table_export_counts_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(stats_ptr)))
+
+    def merge_counts_device(self, tables_ptr: int, n_tables: int, stride: int, own: int):
+        """n_tables exported tables (stride 64-bit words apart) added into this context's table and counters, all but table `own`."""
+        check(lib().mm_table_merge_counts_device(self._h, C.c_void_p(tables_ptr), int(n_tables), int(stride), int(own)))
 
     def import_table_device(self, keys_ptr: int, sums_ptr: int, n: int = 65536, chunk: int = 0, n_chunks: int = 1):
         check(lib().mm_table_import_device(self._h, C.c_void_p(keys_ptr), C.c_void_p(sums_ptr), int(n), int(chunk), int(n_chunks)))

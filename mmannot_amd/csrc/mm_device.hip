@@ -2403,6 +2403,55 @@ __global__ __launch_bounds__(256) void k_synth(const SynthDev S, int4 *__restric
   }
 }
 
+// Rows of the table for the host (mm_get_rows), in slot order: interleaved (set, value) pairs behind a count, so that the read-back is
+// one short copy instead of the three 512-KB arrays (the table holds 10^2..10^4 rows of its 65 536 slots).  Two small launches: every
+// workgroup counts the rows among its 1024 slots; then it adds up the counts of the workgroups before it (at most 63 values), scans
+// its own flags and writes its rows where they belong.
+#define ROWS_WG (GT_CAP / 1024u)
+__device__ __forceinline__ bool row_live(const GlobalTable &G, int ratio, u32 i) { return G.key[i] != 0 && (ratio || G.cnt[i] != 0); }
+__global__ __launch_bounds__(1024) void k_rows_count(GlobalTable G, int ratio, u32 *__restrict__ wgCount) {
+  __shared__ u32 n;
+  if (threadIdx.x == 0) n = 0;
+  __syncthreads();
+  const u64 b = __ballot(row_live(G, ratio, blockIdx.x * 1024u + threadIdx.x));
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n, (u32) __popcll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) wgCount[blockIdx.x] = n;
+}
+__global__ __launch_bounds__(1024) void k_rows_write(GlobalTable G, int ratio, const u32 *__restrict__ wgCount, u64 *__restrict__ out) {
+  __shared__ u32 wsum[16];
+  const u32 t = threadIdx.x, lane = t & 63, w = t >> 6, i = blockIdx.x * 1024u + t;
+  u32 base = 0;
+  for (u32 q = 0; q < blockIdx.x; ++q) base += wgCount[q];
+  if (blockIdx.x == ROWS_WG - 1 && t == 0) out[0] = (u64) (base + wgCount[blockIdx.x]);
+  const bool live = row_live(G, ratio, i);
+  const u64 b = __ballot(live);
+  if (lane == 0) wsum[w] = (u32) __popcll(b);
+  __syncthreads();
+  u32 pos = base + (u32) __popcll(b & ((1ull << lane) - 1ull));
+  for (u32 q = 0; q < w; ++q) pos += wsum[q];
+  if (live) {
+    out[1 + 2 * (size_t) pos] = G.key[i];
+    out[2 + 2 * (size_t) pos] = ratio ? (u64) __double_as_longlong(G.sum[i]) : (u64) __double_as_longlong((double) G.cnt[i]);
+  }
+}
+
+// Tables of other ranks (mm_table_export_counts_device layout: sets, counts, counters - `stride` words per table) added into this
+// context's own table and counters; table `skip` is this context's own.
+__global__ __launch_bounds__(256) void k_table_merge(const u64 *__restrict__ tabs, u32 n_tables, u32 stride, u32 skip, GlobalTable G, u64 *__restrict__ stats) {
+  const u32 total = n_tables * GT_CAP;
+  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const u32 r = j / GT_CAP, i = j % GT_CAP;
+    if (r == skip) continue;
+    const u64 k = tabs[(size_t) r * stride + i], n = tabs[(size_t) r * stride + GT_CAP + i];
+    if (k && n) gt_add(G, k, n);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n_tables * 8u) {
+    const u32 r = threadIdx.x >> 3, q = threadIdx.x & 7u;
+    if (r != skip && q < MM_N_STATS) atomicAdd(&stats[q], tabs[(size_t) r * stride + 2 * (size_t) GT_CAP + q]);
+  }
+}
+
 // ============================================================================= host side
 struct mm_index {
   int device = 0;
@@ -2485,6 +2534,7 @@ struct mm_ctx {
   // persistent state
   GlobalTable G{};
   u64 *d_stats = nullptr, *d_walk = nullptr;
+  u64 *d_rows = nullptr, *h_rows = nullptr;   // mm_get_rows: count + (set, value) pairs, device and pinned host
   u64 qcap = 0;
   u32 *d_grpRem = nullptr;
   u64 *d_grpU = nullptr;
@@ -3005,6 +3055,8 @@ extern "C" int mm_ctx_create(mm_ctx **out, const mm_index *ix, const mm_options 
   HIPCHK(hipMalloc((void **) &c->G.sum, GT_CAP * 8)); HIPCHK(hipMalloc((void **) &c->G.err, 4));
   c->G.nearProbes = c->opt.strategy == MM_STRAT_RATIO ? GT_NEAR_PROBES : 0u;
   HIPCHK(hipMalloc((void **) &c->d_stats, 8 * sizeof(u64))); HIPCHK(hipMalloc((void **) &c->d_walk, 4 * sizeof(u64)));
+  HIPCHK(hipMalloc((void **) &c->d_rows, (1 + 2 * (size_t) GT_CAP + ROWS_WG) * 8));   // (+ the workgroups' row counts)
+  HIPCHK(hipHostMalloc((void **) &c->h_rows, (1 + 2 * (size_t) GT_CAP) * 8, hipHostMallocDefault));
   HIPCHK(hipMalloc((void **) &c->d_rowTot, (RS_ROW_COUNT + 2) * 4));   // + the scan's "workgroups done" counter
   HIPCHK(hipMemset(c->d_rowTot, 0, (RS_ROW_COUNT + 2) * 4)); HIPCHK(hipMalloc((void **) &c->d_M, INFO_WORDS * 4));
   HIPCHK(hipMalloc((void **) &c->d_seg, 2 * GT_CAP * 4));
@@ -3024,6 +3076,7 @@ extern "C" void mm_ctx_destroy(mm_ctx *c) {
   if (c->ev_handoff) (void) hipEventDestroy(c->ev_handoff);
   ctx_free_batch(c);
   (void) hipFree(c->G.key); (void) hipFree(c->G.cnt); (void) hipFree(c->G.sum); (void) hipFree(c->G.err);
+  (void) hipFree(c->d_rows); if (c->h_rows) (void) hipHostFree(c->h_rows);
   (void) hipFree(c->d_stats); (void) hipFree(c->d_walk); (void) hipFree(c->d_rowTot); (void) hipFree(c->d_M); (void) hipFree(c->d_seg);
   (void) hipFree(c->d_grpRem); (void) hipFree(c->d_grpU);
   (void) hipFree(c->d_bLo); (void) hipFree(c->d_bHi); (void) hipFree(c->d_bList);
@@ -3648,25 +3701,53 @@ extern "C" int mm_get_stats(mm_ctx *c, uint64_t stats[MM_N_STATS]) {
   return MM_OK;
 }
 
+#define ROWS_FIRST 8192u   // rows that travel with the count in the first copy (128 KB)
 extern "C" int mm_get_rows(mm_ctx *c, uint64_t *masks, double *sums, size_t cap, size_t *n_rows) {
   if (!c || !n_rows) return fail(MM_ERR_ARG, "mm_get_rows: null argument");
   HIPCHK(hipSetDevice(c->ix->device));   // (one host thread may drive contexts on several devices)
-  std::vector<u64> k(GT_CAP), v(GT_CAP);
-  std::vector<double> s(GT_CAP);
-  HIPCHK(hipMemcpyAsync(k.data(), c->G.key, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(v.data(), c->G.cnt, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(s.data(), c->G.sum, GT_CAP * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
   const bool ratio = c->opt.strategy == MM_STRAT_RATIO;
-  size_t nr = 0;
-  for (u32 i = 0; i < GT_CAP; ++i) {
-    if (!k[i]) continue;
-    if (!ratio && v[i] == 0) continue;  // slot created but never counted cannot happen outside ratio; be safe
-    if (masks && nr < cap) { masks[nr] = k[i]; if (sums) sums[nr] = ratio ? s[i] : (double) v[i]; }
-    ++nr;
-  }
+  u32 *const wgCount = (u32 *) (c->d_rows + 1 + 2 * (size_t) GT_CAP);
+  hipLaunchKernelGGL(k_rows_count, dim3(ROWS_WG), dim3(1024), 0, c->stream, c->G, ratio ? 1 : 0, wgCount);
+  hipLaunchKernelGGL(k_rows_write, dim3(ROWS_WG), dim3(1024), 0, c->stream, c->G, ratio ? 1 : 0, (const u32 *) wgCount, c->d_rows);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_rows, c->d_rows, (1 + 2 * (size_t) ROWS_FIRST) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const size_t nr = (size_t) c->h_rows[0];
   *n_rows = nr;
-  if (masks && nr > cap) return fail(MM_ERR_ARG, "mm_get_rows: capacity too small");
+  if (!masks) return MM_OK;
+  if (nr > cap) return fail(MM_ERR_ARG, "mm_get_rows: capacity too small");
+  if (nr > ROWS_FIRST) {
+    HIPCHK(hipMemcpyAsync(c->h_rows + 1 + 2 * (size_t) ROWS_FIRST, c->d_rows + 1 + 2 * (size_t) ROWS_FIRST, 2 * (nr - ROWS_FIRST) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  for (size_t i = 0; i < nr; ++i) {
+    masks[i] = c->h_rows[1 + 2 * i];
+    if (sums) memcpy(&sums[i], &c->h_rows[2 + 2 * i], 8);
+  }
+  return MM_OK;
+}
+
+// The table for a merge on the device (ranks of a multi-process job, -y default / unique: tables add up): the 65 536 sets, their
+// integer counts and the seven counters (d_stats[MM_N_STATS]), device to device on the context's stream - nothing waits for the host.
+extern "C" int mm_table_export_counts_device(mm_ctx *c, uint64_t *d_keys, uint64_t *d_counts, uint64_t *d_stats) {
+  if (!c || !d_keys || !d_counts || !d_stats) return fail(MM_ERR_ARG, "mm_table_export_counts_device: null argument");
+  if (c->opt.strategy == MM_STRAT_RATIO) return fail(MM_ERR_STATE, "mm_table_export_counts_device: -y ratio sums are not mergeable by addition (mm_table_export_device)");
+  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(hipMemcpyAsync(d_keys, c->G.key, GT_CAP * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_counts, c->G.cnt, GT_CAP * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_stats, c->d_stats, MM_N_STATS * 8, hipMemcpyDeviceToDevice, c->stream));
+  return MM_OK;
+}
+// ... and the other direction: n_tables tables in that layout, `stride` 64-bit words apart (>= 2 * MM_TABLE_SLOTS + MM_N_STATS; as an
+// all_gather of every rank's export leaves them), are added to this context's table and counters - all but table `own`, which is this
+// context's.  Asynchronous on the context's stream; the tables must be complete when it is called.  mm_get_rows / mm_get_stats then
+// give the whole job's result, the same on every rank.
+extern "C" int mm_table_merge_counts_device(mm_ctx *c, const uint64_t *d_tables, size_t n_tables, size_t stride, size_t own) {
+  if (!c || !d_tables || n_tables == 0 || n_tables > 32 || stride < 2 * (size_t) GT_CAP + MM_N_STATS) return fail(MM_ERR_ARG, "mm_table_merge_counts_device: bad argument (1..32 tables)");
+  if (c->opt.strategy == MM_STRAT_RATIO) return fail(MM_ERR_STATE, "mm_table_merge_counts_device: -y ratio sums are not mergeable by addition");
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipLaunchKernelGGL(k_table_merge, dim3(256), dim3(256), 0, c->stream, (const u64 *) d_tables, (u32) n_tables, (u32) stride, (u32) std::min<size_t>(own, 0xFFFFFFFFu), c->G, c->d_stats);
+  HIPCHK(hipGetLastError());
   return MM_OK;
 }
 

@@ -37,6 +37,8 @@ def warm_up(device=None, group=None, p2p: bool = False) -> None:
     dist.all_gather([torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)], x, group=group)
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     dist.broadcast(x, src=ws - 1, group=group)
+    if dev.type != "cpu":
+        dist.all_gather_into_tensor(torch.zeros(ws, dtype=torch.int64, device=dev), x, group=group)
     if p2p:
         if rank > 0:
             dist.recv(x, src=rank - 1, group=group)
@@ -74,6 +76,39 @@ def merge_counts(masks: np.ndarray, sums: np.ndarray, stats: Dict[str, int], dev
     out = dense.cpu().numpy()
     mk = dictionary.cpu().numpy().view(np.uint64)
     return mk, out[:len(mk)].astype(np.float64), {k: int(v) for k, v in zip(names, out[len(mk):])}
+
+
+def merge_counts_device(counter, device, group=None, rehearsal: bool = False) -> Tuple[np.ndarray, np.ndarray, Dict[str, int]]:
+    """The same merge with the tables staying on the devices.  Every rank's table has the same fixed size (Counter.TABLE_SLOTS sets and
+    counts + the seven counters, 1 MB), so ONE all_gather moves everything - no sizes first, no dictionary, no all_reduce - and every
+    rank adds the other ranks' rows into its own table itself (Counter.merge_counts_device: one kernel, integer sums, the same result
+    everywhere), then reads its table back as it would alone.  `device`: the rank's GPU (backend nccl = RCCL over xGMI); with a CPU
+    backend (gloo rehearsals) the buffer takes the detour through host memory that the collective then needs.
+    Returns (masks, sums, stats) like merge_counts (rows in this rank's table order, not sorted).  The counter holds the merged job
+    afterwards.  rehearsal=True: the same calls on empty tables (nothing is added to the counter) - first use of a collective sets up
+    RCCL channels and loads kernels, which a caller may want out of a timed region."""
+    if _alone(group):
+        m, s_ = counter.getCounts()
+        return m, s_, counter.stats()
+    S = counter.TABLE_SLOTS
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.zeros(2 * S + 8, dtype=torch.int64, device=device)
+    if not rehearsal:
+        counter.export_counts_device(mine.data_ptr(), mine[S:].data_ptr(), mine[2 * S:].data_ptr())
+    counter.sync()                                    # (the export ran on the context's stream, the collective runs on RCCL's)
+    if dist.get_backend(group) != "nccl":             # (CPU backend: gloo rehearsals)
+        src = mine.cpu()
+        parts = [torch.empty_like(src) for _ in range(ws)]
+        dist.all_gather(parts, src, group=group)
+        allt = torch.cat(parts).to(device)
+    else:
+        allt = torch.empty(ws * (2 * S + 8), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allt, mine, group=group)
+    torch.cuda.current_stream(device).synchronize()   # (the gathered tables are complete before the context's stream reads them)
+    counter.merge_counts_device(allt.data_ptr(), ws, 2 * S + 8, rank)
+    stats = counter.stats()                           # (synchronises the context's stream: allt may go)
+    m, s_ = counter.getCounts()
+    return m, s_, stats
 
 
 def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunks: int = 1):

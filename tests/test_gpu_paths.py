@@ -235,3 +235,53 @@ def test_every_kind_of_bin_of_the_pipelined_probe(gpu_lib, oracle, strategy, l, 
     assert ctr.stats() == ref.stats
     assert ps["fast_slot_bytes"] > 0 and 0 < ps["passed_on"] < 0.5 * len(aln), ps
     ctr.close(); index.close()
+
+
+@pytest.mark.parametrize("strategy", ["default", "unique"])
+@pytest.mark.parametrize("n_parts", [2, 5])
+def test_tables_merge_on_the_device(gpu_lib, oracle, strategy, n_parts):
+    """Counter.export_counts_device / merge_counts_device (what dist.merge_counts_device does between ranks, here between contexts of one
+    process): reads dealt out by name over n_parts contexts, every context's table exported into one buffer - the layout an all_gather
+    leaves - and merged into context 0: table and counters of the whole input (Counter::getCounts summed over shards,
+    mmannot.cpp:1803).  Under -y ratio both calls refuse."""
+    import torch
+    mm = gpu_lib
+    rng = np.random.default_rng(77 + n_parts)
+    desc = sr.random_config(rng, n_lines=6, max_per_line=3)
+    ix = sr.random_index(rng, desc.E, nchr=3, n=4000, maxpos=300_000, skip_chr=None)
+    reads = sr.random_reads(rng, ix, n=30_000, nchr=3, maxpos=300_000, nh_max=6)
+    ref = oracle.run(desc, ix, reads, overlap=-1.0, strandedness="F", strategy=strategy)
+    cfg = to_cfg(mm, desc)
+    index = mm.IntervalIndex(cfg, ix["chr"], ix["start"], ix["end"], ix["type"], ix["strand"], ix["n_chromosomes"])
+    S = mm.Counter.TABLE_SLOTS
+    stride = 2 * S + 8
+    buf = torch.zeros(n_parts * stride, dtype=torch.int64, device="cuda:0")
+    ctrs = []
+    for p in range(n_parts):
+        m = reads["qid"] % n_parts == p                    # every hit of a name in one context (mmannot.cpp:1669-1701)
+        ctr = mm.Counter(index, overlap=-1.0, strandedness="F", strategy=strategy)
+        if m.any():
+            ctr.add_batch(mm.pack_alignments(reads["tid"][m], reads["start"][m], reads["end"][m], reads["strand"][m], reads["qid"][m]),
+                          reads["nh"][m].astype(np.uint32), int(reads["qid"].max()) + 1)
+        ctr.flush()
+        base = buf.data_ptr() + 8 * p * stride
+        ctr.export_counts_device(base, base + 8 * S, base + 16 * S)
+        ctr.sync()
+        ctrs.append(ctr)
+    ctrs[0].merge_counts_device(buf.data_ptr(), n_parts, stride, 0)
+    stats = ctrs[0].stats()
+    masks, sums = ctrs[0].getCounts()
+    assert stats == ref.stats
+    t = mm.TableCount(cfg, 1); t.add_rows(masks, sums)
+    assert t.dump(["test_dataset"]) == oracle.format_table(desc, ref.row_mask, ref.row_count, "test_dataset")
+    r = mm.Counter(index, overlap=-1.0, strandedness="F", strategy="ratio")
+    with pytest.raises(mm.MMError):
+        r.export_counts_device(buf.data_ptr(), buf.data_ptr() + 8 * S, buf.data_ptr() + 16 * S)
+    with pytest.raises(mm.MMError):
+        r.merge_counts_device(buf.data_ptr(), n_parts, stride, 0)
+    with pytest.raises(mm.MMError):
+        ctrs[0].merge_counts_device(buf.data_ptr(), 33, stride, 0)
+    r.close()
+    for c in ctrs:
+        c.close()
+    index.close()
