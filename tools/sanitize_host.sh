@@ -22,7 +22,7 @@ extern "C" int mm_sync(mm_ctx *) { return MM_ERR_HIP; }
 extern "C" size_t mm_ratio_pending(const mm_ctx *) { return 0; }
 extern "C" uint32_t mm_row_chunk(uint64_t mask, uint32_t n) { return n <= 1 ? 0u : (uint32_t) ((mask * 0x9E3779B97F4A7C15ull) >> 40) % n; }
 EOS
-if [ "$KIND" = thread ]; then SAN="-fsanitize=thread"; RT=$(g++ -print-file-name=libtsan.so); TESTS="tests/test_decoder.py";
+if [ "$KIND" = thread ]; then SAN="-fsanitize=thread"; RT=$(g++ -print-file-name=libtsan.so); TESTS="tests/test_decoder.py tests/test_partition.py";
 else SAN="-fsanitize=address,undefined"; RT=$(g++ -print-file-name=libasan.so); TESTS="tests/test_decoder.py tests/test_builder.py tests/test_kat.py tests/test_synth_e2e.py tests/test_addnh.py tests/test_partition.py"; fi
 g++ -std=c++17 -g -O1 $SAN -fno-omit-frame-pointer -shared -fPIC -I include -o "$OUT/libmm_host_san.so" \
     mmannot_amd/csrc/mm_annot.cpp mmannot_amd/csrc/mm_reads.cpp mmannot_amd/csrc/mm_host.cpp mmannot_amd/csrc/mm_multi.cpp "$OUT/stub.cpp" -lz -lpthread
