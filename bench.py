@@ -660,7 +660,7 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     from oracle import mm_oracle as mo
     read_len, nh_max, scatter, strategy = wl["read_len"], wl["nh_max"], wl["scatter"], wl["strategy"]
     flags = ["-s", wl["strand"]] + (["-l", "%g" % wl["overlap"]] if wl["overlap"] >= 0 else []) + (["-y", strategy] if strategy != "default" else [])
-    S = host_cores()
+    S = min(host_cores(), 32)       # (a bounded sample also in memory: every reference process holds the annotation and its read-name maps)
     # bounded sample: S shards of ~8 s of reference work each (measured on the 16-core share of an MI355X box: 2^22 alignments take the
     # reference 2.1 s beside 2.5 s of GTF loading - the quotient would rest on the smaller half; 2^24 is 3.4x the loading time)
     n = 1 << (24 if S <= 16 else (23 if S <= 32 else 22))
