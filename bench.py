@@ -720,7 +720,7 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     shutil.rmtree(d, ignore_errors=True)
     return {"value": rate, "unit": "alignments/s", "cores": S, "kind": "reference",
             "sample": f"{S} BAM shards x 2^{n.bit_length() - 1} alignments of rank 0's stream, {S} concurrent single-thread processes of "
-                      f"oracle/_ref/mmannot_patched (its own -t races) = every host core this process may use: {t_full:.1f} s, {t_fixed:.1f} s of it "
+                      f"oracle/_ref/mmannot_patched (its own -t races) = {'every host core this process may use' if S == host_cores() else f'{S} of the {host_cores()} host cores this process may use'}: {t_full:.1f} s, {t_fixed:.1f} s of it "
                       f"GTF/config loading (measured the same way, subtracted); one shard alone: {n / max(1e-9, t_one - t_fixed1):.3g} alignments/s",
             "parity_table_vs_reference": bool(parity)}
 
