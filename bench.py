@@ -197,6 +197,11 @@ def main():
         hi = -((-end) // W_sc) * W_sc
         return min(qb_all, (hi // T_grp + 2) * nh_max + 2)
 
+    def ratio_block(r, s_):       # strong, -y ratio: rank r's s_-th batch of the job's nb * Bg tuples = (first tuple, number of tuples).
+        tot = nb * Bg             # Rank r holds the r-th of `world` consecutive blocks (the remainder of the division spread over the
+        lo, hi = tot * r // world, tot * (r + 1) // world          # blocks, nothing dropped), each cut into nb batches
+        return lo + (hi - lo) * s_ // nb, (hi - lo) * (s_ + 1) // nb - (hi - lo) * s_ // nb
+
     alns, qlo_of, qbound_of = [], [], []
     if not strong:
         B = Bg
@@ -216,17 +221,22 @@ def main():
             qlo_of.append(stream_qlo(s_ * Bg) // world); qbound_of.append(min(qb, stream_qbound((s_ + 1) * Bg, qb_job) // world + 2))
             del g, q
         B = max(1, Bg // world)
-    else:                        # strong, -y ratio: consecutive blocks
-        B = max(1 << 12, Bg // world)
-        qb = stream_qb(world * nb * B)
+    else:                        # strong, -y ratio: consecutive blocks of the same nb * Bg tuples for every N
+        B = max(1, Bg // world)
+        qb = stream_qb(nb * Bg)
         for s_ in range(nb):
-            first = (rank * nb + s_) * B
-            alns.append(gen(job_seed, first, B))
-            qlo_of.append(stream_qlo(first)); qbound_of.append(stream_qbound(first + B, qb))
+            first, cnt = ratio_block(rank, s_)
+            alns.append(gen(job_seed, first, cnt) if cnt else torch.empty((0, 4), dtype=torch.int32, device=dev))
+            qlo_of.append(stream_qlo(first)); qbound_of.append(stream_qbound(first + cnt, qb))
     torch.cuda.synchronize()
     sizes = [int(a.shape[0]) for a in alns]
-    total_tuples = (world * nb * B) if (not strong or not by_name) else nb * Bg
-    job_tuples_timed = (world * args.steps * B) if (not strong or not by_name) else args.steps * Bg
+    if not strong:
+        total_tuples, job_tuples_timed = world * nb * B, world * args.steps * B
+    elif by_name:
+        total_tuples, job_tuples_timed = nb * Bg, args.steps * Bg
+    else:                        # (every rank's first `warmup` batches are its warm-up: what is timed is the rest of every block)
+        total_tuples = nb * Bg
+        job_tuples_timed = sum(ratio_block(r, s_)[1] for r in range(world) for s_ in range(args.warmup, nb))
 
     def qlo(step):
         return qlo_of[step]
@@ -359,7 +369,7 @@ def main():
     merge_check = None
     if multi and rank == 0:
         lead_ = res_dev if res_dev is not None else res_host
-        merge_check = check_against_one_gpu(mm, torch, index, wl, gen, dict(strong=strong, by_name=by_name, world=world, nb=nb, B=B, Bg=Bg,
+        merge_check = check_against_one_gpu(mm, torch, index, wl, gen, dict(strong=strong, by_name=by_name, world=world, nb=nb, B=B, Bg=Bg, ratio_block=ratio_block,
                                                                                job_seed=job_seed, single=single, nh_max=nh_max),
                                             (stream_qb, stream_qlo, stream_qbound), lead_[2], lead_[3], lead_[4])
         assert merge_check["verified"], merge_check
@@ -539,9 +549,11 @@ def check_against_one_gpu(mm, torch, index, wl, gen, J, qfun, masks, sums, stats
     elif strategy == "ratio":                 # file order = rank order: one context, never cleared
         for r in range(world):
             for s_ in range(nb):
-                first = (r * nb + s_) * B if J["strong"] else s_ * B
-                a = gen(J["job_seed"] + (0 if J["strong"] else r), first, B)
-                ctr.add_batch_device(a.data_ptr(), B, 1, single_hit=J["single"])
+                first, cnt = J["ratio_block"](r, s_) if J["strong"] else (s_ * B, B)
+                if cnt == 0:
+                    continue
+                a = gen(J["job_seed"] + (0 if J["strong"] else r), first, cnt)
+                ctr.add_batch_device(a.data_ptr(), cnt, 1, single_hit=J["single"])
                 ctr.sync()
         take()
         how = "every rank's block in rank order through one context"
