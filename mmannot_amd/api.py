@@ -212,6 +212,7 @@ class Counter:
         h = C.c_void_p()
         check(lib().mm_ctx_create(C.byref(h), index._h, C.byref(opt), C.c_void_p(stream) if stream else None))
         self._h = h
+        self.stream = stream or 0   # the HIP stream handle the context was given (0: a stream of its own)
         self._keep = []  # host buffers that must outlive the async copy
 
     def clear(self):  # Counter::clear mmannot.cpp:1742-1747

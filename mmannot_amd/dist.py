@@ -154,6 +154,9 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunk
         # until the chain's last replay is enqueued.  Rows are independent of each other, so the chain is pipelined by row chunks: a
         # rank works on chunk c + 1 while the next one replays chunk c.
         S = counter.TABLE_SLOTS
+        # (send / recv are ordered against torch's current stream.  A context created on that stream - bench.py's are - needs nothing
+        # more; one with a stream of its own is synchronised by hand around every hand-over: correct, just not overlapped)
+        foreign = getattr(counter, "stream", 0) != torch.cuda.current_stream(dev).cuda_stream
         bufs = [torch.zeros(2 * S, dtype=torch.int64, device=dev) for _ in range(2)]       # (a send may still be reading the previous chunk's)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_chunks)]
         for c in range(n_chunks):
@@ -161,10 +164,14 @@ def chain_ratio(counter, stats: Dict[str, int], device=None, group=None, n_chunk
             ev[c][0].record()
             if rank > 0:
                 dist.recv(buf, src=rank - 1, group=group)
+                if foreign:
+                    torch.cuda.current_stream(dev).synchronize()
                 counter.import_table_device(buf.data_ptr(), buf.data_ptr() + 8 * S, S, c, n_chunks)
             counter.ratio_replay(0, 1 << 62, c, n_chunks)
             if rank < ws - 1:
                 counter.export_table_device(buf.data_ptr(), buf.data_ptr() + 8 * S)
+                if foreign:
+                    counter.sync()
                 dist.send(buf, dst=rank + 1, group=group)
             ev[c][1].record()
         counter.ratio_release()
