@@ -89,9 +89,9 @@ def main():
                     "(the line of record needs them: roofline.avg_launch_ms)")
     ap.add_argument("--legs", default="both", choices=("both", "host", "resident"), help="profiling aid: run only one leg (the JSON line of record needs both)")
     ap.add_argument("--tuple-bytes", type=int, default=16, choices=(16, 12),
-                    help="bytes per tuple on the link in the from-host leg that gives `value`: 16 = mm_aln (SURVEY.md 8d, the metric of record); "
+                    help="bytes per tuple on the link in the from-host leg (`from_host`): 16 = mm_aln (SURVEY.md 8d); "
                          "12 = the packed link format (mm_pack12 where the tuples are produced, expanded on the device).  With 16 the packed "
-                         "format is still measured, in a leg of its own, and reported beside `value` as `from_host_packed12`")
+                         "format is still measured, in a leg of its own, and reported as `from_host_packed12`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=24)
     args = ap.parse_args()
