@@ -456,7 +456,11 @@ def main():
         out["phase_pass"] = f"separate untimed pass of {n_phase} resident steps with events around every phase"
         if want_cpu:
             port = cpu_baseline(args, an, wl, gen_len)
-            ref = cpu_baseline_reference(args, an, wl, gen_len, index, cfg)
+            try:
+                ref = cpu_baseline_reference(args, an, wl, gen_len, index, cfg)
+            except Exception as e:          # (a full /tmp, a killed worker ...: the line of record must not be lost with the baseline)
+                ref = None
+                port["reference_error"] = f"{type(e).__name__}: {e}"[:300]
             if ref is not None:
                 ref["port_single_thread"] = {k: port[k] for k in ("value", "sample")}
                 out["cpu_baseline"] = ref
