@@ -681,6 +681,9 @@ def cpu_baseline_reference(args, an, wl, chr_len, index, cfg):
     # reference 2.1 s beside 2.5 s of GTF loading - the quotient would rest on the smaller half; 2^24 is 3.4x the loading time)
     n = 1 << (24 if S <= 16 else (23 if S <= 32 else 22))
     d = tempfile.mkdtemp(prefix="mmbench")
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, d, ignore_errors=True)      # (also when something below raises: the shards are gigabytes)
     gtf = os.path.join(d, "a.gtf"); open(gtf, "w").write(synth.gtf_text(an))
     cfgp = os.path.join(d, "c.cfg"); open(cfgp, "w").write(synth.config_text(an.shape))
     chroms = [(c, int(l)) for c, l in zip(an.chr_names, an.chr_len)]
